@@ -1,0 +1,246 @@
+// bmm_spec.h -- the numerics of the allocation path, written once for host and device.
+//
+// Everything the categorical draw of z_n depends on is defined here with IEEE-754
+// binary64 add / mul / fma / div / sqrt / floor and integer bit operations only, in a
+// fixed order, so that a gfx950 wave and an x86 core produce the same bits (the build
+// passes -ffp-contract=off to both compilers; every fused operation is an explicit
+// bmm::fma_). No libm transcendental is called: log/exp are implemented below.
+// tests/test_gpu_math.py checks device-vs-host bit equality of every function here;
+// oracle/bmm_oracle.c restates the same arithmetic independently in plain C.
+//
+// Reference arithmetic being restated (all /root/reference):
+//   collapsed conditional   src/collapsed_gibbs.cpp:99-137
+//   DP conditional          src/collapsed_gibbs_dp.cpp:71,102-106,140-186
+//   stick-breaking z-step   src/stickbreaking.cpp:75-105
+//   alpha update            src/utils.cpp:6-14
+// The reference draws through R's Mersenne-Twister (rmultinom / rbeta / rgamma); this
+// build draws through Philox4x32-10 (counter-based, Salmon et al. 2011), see DESIGN.md.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BMM_HD __host__ __device__ __forceinline__
+#else
+#define BMM_HD inline
+#endif
+
+namespace bmm {
+
+// ---------------------------------------------------------------- constants
+constexpr int kGroupW = 4;             // features per lookup group (nibble tables)
+constexpr int kGroupM = 1 << kGroupW;  // entries per group table
+
+// Philox stream ids (counter word 3)
+enum : uint32_t {
+    kStreamZ = 0,        // c0,c1 = observation index, c2 = sweep
+    kStreamStickA = 1,   // v_k ~ Beta: first gamma;  c0 = k, c1 = block counter, c2 = sweep
+    kStreamStickB = 2,   // v_k ~ Beta: second gamma
+    kStreamThetaA = 3,   // theta_kd ~ Beta: first gamma; c0 = k*P+d
+    kStreamThetaB = 4,
+    kStreamAlphaEta = 5, // eta ~ Beta(alpha+1, N): first gamma (c0 = 0), second gamma (c0 = 1)
+    kStreamAlphaG1 = 6,  // Gamma(a+K)
+    kStreamAlphaG2 = 7,  // Gamma(a+K-1)
+};
+
+// ---------------------------------------------------------------- bit helpers
+BMM_HD uint64_t dbits(double x) {
+    union { double d; uint64_t u; } c; c.d = x; return c.u;
+}
+BMM_HD double dfrom(uint64_t u) {
+    union { double d; uint64_t u; } c; c.u = u; return c.d;
+}
+BMM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BMM_HD double floor_(double a) { return __builtin_floor(a); }
+// IEEE correctly-rounded on both sides (checked bitwise on the GPU by test_gpu_math).
+BMM_HD double div_(double a, double b) { return a / b; }
+BMM_HD double sqrt_(double a) { return __builtin_sqrt(a); }
+
+BMM_HD double neg_inf() { return dfrom(0xfff0000000000000ull); }
+BMM_HD double pos_inf() { return dfrom(0x7ff0000000000000ull); }
+BMM_HD double qnan() { return dfrom(0x7ff8000000000000ull); }
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+
+BMM_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+BMM_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
+}
+
+// 53-bit uniform in [0,1) from two 32-bit words.
+BMM_HD double u01(uint32_t a, uint32_t b) {
+    const double hi = (double)(a >> 5), lo = (double)(b >> 6);
+    return (hi * 67108864.0 + lo) * 1.1102230246251565404e-16;  // 2^-53
+}
+// uniform in (0,1]: 1 - u01
+BMM_HD double u01_open0(uint32_t a, uint32_t b) { return 1.0 - u01(a, b); }
+
+// A counted stream of Philox blocks: (c0, block counter, c2, stream id) under one key.
+struct Stream {
+    uint32_t c0, ctr, c2, sid, k0, k1;
+    BMM_HD U4 next() { U4 r = philox4x32_10(c0, ctr, c2, sid, k0, k1); ++ctr; return r; }
+};
+BMM_HD Stream make_stream(uint64_t seed, uint32_t c0, uint32_t c2, uint32_t sid) {
+    Stream s; s.c0 = c0; s.ctr = 0; s.c2 = c2; s.sid = sid;
+    s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); return s;
+}
+
+// The uniform that decides z_i in sweep j (one Philox block per observation per sweep).
+BMM_HD double z_uniform(uint64_t seed, uint64_t i, uint32_t sweep) {
+    const U4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), sweep, kStreamZ,
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    return u01(r.x, r.y);
+}
+
+// ---------------------------------------------------------------- log / exp
+// log(x): argument reduced to m in [sqrt(1/2), sqrt(2)), f = m-1, s = f/(2+f),
+// log(1+f) = f - f^2/2 + s*(f^2/2 + R(s^2)), R an even minimax polynomial of degree 14
+// (coefficients: the classic Remez set for this reduction). Error < 1 ulp.
+BMM_HD double log_(double x) {
+    uint64_t ix = dbits(x);
+    if (x == 0.0) return neg_inf();
+    if ((int64_t)ix < 0) return qnan();
+    if ((ix >> 52) == 0x7ffull) return x;  // +inf, nan
+    int e = 0;
+    if ((ix >> 52) == 0) {  // subnormal: scale by 2^54
+        x = x * 18014398509481984.0; ix = dbits(x); e = -54;
+    }
+    e += (int)(ix >> 52) - 1023;
+    uint64_t m = (ix & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    if (m >= 0x3ff6a09e667f3bcdull) { m -= 0x0010000000000000ull; e += 1; }
+    const double f = dfrom(m) - 1.0;
+    const double s = div_(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double t1 = w * fma_(w, fma_(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_(w, fma_(w, fma_(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// exp(x): k = round(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r, scale by 2^k.
+// Results below 2^-1021 are flushed to 0 (x < -708); the sampler never needs them.
+BMM_HD double exp_(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return pos_inf();
+    if (x < -708.0) return 0.0;
+    const double kd = floor_(fma_(x, 1.44269504088896338700e+00, 0.5));
+    double r = fma_(-kd, 6.93147180369123816490e-01, x);
+    r = fma_(-kd, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;            // 1/13!
+    p = fma_(p, r, 2.0876756987868098979e-09);       // 1/12!
+    p = fma_(p, r, 2.5052108385441718775e-08);       // 1/11!
+    p = fma_(p, r, 2.7557319223985890653e-07);       // 1/10!
+    p = fma_(p, r, 2.7557319223985892511e-06);       // 1/9!
+    p = fma_(p, r, 2.4801587301587301566e-05);       // 1/8!
+    p = fma_(p, r, 1.9841269841269841253e-04);       // 1/7!
+    p = fma_(p, r, 1.3888888888888889419e-03);       // 1/6!
+    p = fma_(p, r, 8.3333333333333332177e-03);       // 1/5!
+    p = fma_(p, r, 4.1666666666666664354e-02);       // 1/4!
+    p = fma_(p, r, 1.6666666666666665741e-01);       // 1/3!
+    p = fma_(p, r, 0.5);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    int k = (int)kd;
+    if (k > 1023) { p = p * 2.0; k -= 1; }
+    return p * dfrom((uint64_t)(k + 1023) << 52);
+}
+
+// ---------------------------------------------------------------- variates
+// Standard normal by the Marsaglia polar method (log and sqrt only).
+BMM_HD double rnorm_(Stream& st) {
+    for (;;) {
+        const U4 r = st.next();
+        const double v1 = 2.0 * u01(r.x, r.y) - 1.0, v2 = 2.0 * u01(r.z, r.w) - 1.0;
+        const double s = v1 * v1 + v2 * v2;
+        if (s < 1.0 && s > 0.0) return v1 * sqrt_(div_(-2.0 * log_(s), s));
+    }
+}
+
+// Gamma(shape, scale 1), Marsaglia & Tsang (2000); shape < 1 by the u^(1/shape) boost.
+BMM_HD double rgamma_(double shape, Stream& st) {
+    if (!(shape > 0.0)) return 0.0;  // R::rgamma(0, .) is 0
+    double boost = 1.0;
+    if (shape < 1.0) {
+        const U4 r = st.next();
+        boost = exp_(div_(log_(u01_open0(r.x, r.y)), shape));
+        shape = shape + 1.0;
+    }
+    const double d = shape - 0.33333333333333331483;
+    const double c = div_(1.0, sqrt_(9.0 * d));
+    for (;;) {
+        const double x = rnorm_(st);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const U4 r = st.next();
+        const double u = u01_open0(r.x, r.y);
+        const double x2 = x * x;
+        if (log_(u) < 0.5 * x2 + d - d * v + d * log_(v)) return d * v * boost;
+    }
+}
+
+// Beta(p, q) = X / (X + Y), X ~ Gamma(p), Y ~ Gamma(q), two separate streams.
+BMM_HD double rbeta_(double p, double q, Stream& sa, Stream& sb) {
+    const double x = rgamma_(p, sa), y = rgamma_(q, sb);
+    return div_(x, x + y);
+}
+
+// Escobar & West auxiliary-variable update of the concentration (utils.cpp:6-14).
+BMM_HD double update_alpha_(double alpha_old, double a, double b, double N, int K,
+                            uint64_t seed, uint32_t sweep) {
+    Stream s0 = make_stream(seed, 0, sweep, kStreamAlphaEta);
+    Stream s1 = make_stream(seed, 1, sweep, kStreamAlphaEta);
+    const double eta = rbeta_(alpha_old + 1.0, N, s0, s1);
+    const double b_eps = b - log_(eta);
+    const double pi1 = a + (double)K - 1.0;
+    const double pi2 = N * b_eps;
+    const double pi = div_(pi1, pi1 + pi2);
+    Stream g1 = make_stream(seed, 0, sweep, kStreamAlphaG1);
+    Stream g2 = make_stream(seed, 0, sweep, kStreamAlphaG2);
+    const double scale = div_(1.0, b_eps);
+    const double ga = rgamma_(a + (double)K, g1) * scale;
+    const double gb = rgamma_(a + (double)K - 1.0, g2) * scale;
+    return pi * ga + (1.0 - pi) * gb;
+}
+
+// ---------------------------------------------------------------- conditional tables
+// Per-feature log terms of the Beta-Bernoulli predictive of one cluster holding n
+// observations with s1 of them 1 in this feature when the scored observation has x=1,
+// s0 when it has x=0 (collapsed_gibbs.cpp:116-120; the "minus self" variant passes
+// n-1, s-1 and s). `den` = log(beta+gamma+n) is hoisted by the caller.
+BMM_HD double term_x1(double beta, int64_t s1, double den) { return log_(beta + (double)s1) - den; }
+BMM_HD double term_x0(double gamma, int64_t n, int64_t s0, double den) {
+    return log_((gamma + (double)n) - (double)s0) - den;
+}
+
+// One group-table entry: features [g*W, g*W+W) of one cluster under bit pattern m.
+BMM_HD double group_entry(const double* e1, const double* e0, int g, int P, unsigned m) {
+    double t = 0.0;
+    for (int j = 0; j < kGroupW; ++j) {
+        const int d = g * kGroupW + j;
+        if (d < P) t = t + (((m >> j) & 1u) ? e1[d] : e0[d]);
+    }
+    return t;
+}
+
+}  // namespace bmm

@@ -1,0 +1,109 @@
+/* bmm_oracle.h -- CPU oracle for the cluster-allocation path of stulacy/bmm-mcmc.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bmm-mcmc_amd/ may include, link or call
+ * this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY UNPINNED for every RNG-dependent output: the reference (R + Rcpp +
+ * RcppArmadillo + R nmath) cannot be built or run in this image, ships no tests and
+ * no golden vectors, and draws through R's Mersenne-Twister, which a counter-based
+ * device generator cannot reproduce.  What pins this file instead:
+ *   - the RNG-free conditionals are checked against closed-form known answers
+ *     recomputed from the cited reference lines with NumPy (tests/golden/make_kats.py);
+ *   - the bundled datasets' documented generating parameters (R/bmm-mcmc.R:13-17,
+ *     31-35, 46-50) as statistical acceptance bounds;
+ *   - Philox4x32-10 against the Random123 known-answer vectors.
+ *
+ * Two restatements per sampler:
+ *   *_literal : the reference algorithm as written -- per-cluster member lists,
+ *               sums recomputed for every (i,k,d), glibc log/exp, one observation at
+ *               a time (collapsed_gibbs.cpp:84-225, collapsed_gibbs_dp.cpp:98-283,
+ *               stickbreaking.cpp:66-236).  O(N^2 P) per sweep: small N only.
+ *   *_run     : the same chain from cached sufficient statistics, observations
+ *               resampled in batches of `batch` against statistics frozen at batch
+ *               start (own contribution removed exactly), in the build's fixed
+ *               binary64 arithmetic.  batch == 1 is the reference's sequential scan.
+ *               This is what the HIP path must match bit for bit.
+ *
+ * Layouts follow the R objects: X is N x P column-major int32 (element (i,d) at
+ * i + d*N); z_out is S x N column-major, labels 1-based; theta_out is K x P x S
+ * column-major; alpha_out has S entries; S = nsamples - burnin.
+ */
+#ifndef BMM_ORACLE_H
+#define BMM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_NA_INT (-2147483647 - 1) /* R's NA_integer_ */
+
+/* ---- numerics (restated; must equal bmm-mcmc_amd/csrc/bmm_spec.h bit for bit) ---- */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double oracle_u01(uint32_t a, uint32_t b);
+double oracle_z_uniform(uint64_t seed, uint64_t i, uint32_t sweep);
+double oracle_log(double x);
+double oracle_exp(double x);
+double oracle_rgamma(double shape, uint64_t seed, uint32_t c0, uint32_t sweep, uint32_t stream);
+double oracle_rbeta(double p, double q, uint64_t seed, uint32_t c0a, uint32_t c0b, uint32_t sweep,
+                    uint32_t stream_a, uint32_t stream_b);
+double oracle_update_alpha(double alpha_old, double a, double b, double N, int K, uint64_t seed,
+                           uint32_t sweep);
+void oracle_log_array(const double* x, double* y, int64_t n);
+void oracle_exp_array(const double* x, double* y, int64_t n);
+int oracle_group_width(void);
+
+/* ---- RNG-free conditionals of one observation (z is 1-based, i 0-based) ---- */
+/* literal = reference formula with glibc; spec = the build's table arithmetic. */
+void oracle_collapsed_cond_literal(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i,
+                                   int K, double alpha, double beta, double gamma,
+                                   double* raw /*K*/, double* norm /*K*/);
+void oracle_collapsed_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i,
+                                int K, double alpha, double beta, double gamma,
+                                double* score /*K*/, double* norm /*K*/);
+/* DP: existing clusters in label order 1..K then the new-cluster option (K+1 values). */
+void oracle_dp_cond_literal(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i, int K,
+                            double alpha, double beta, double gamma, double* logw /*K+1*/,
+                            double* norm /*K+1*/);
+void oracle_dp_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i, int K,
+                         double alpha, double beta, double gamma, double* logw, double* norm);
+void oracle_sb_cond_literal(const int32_t* X, int64_t N, int P, int64_t i, int K, const double* pi,
+                            const double* theta /*K x P colmajor*/, double* raw, double* norm);
+void oracle_sb_cond_spec(const int32_t* X, int64_t N, int P, int64_t i, int K, const double* pi,
+                         const double* theta, double* score, double* norm);
+
+/* ---- samplers ---- */
+int oracle_collapsed_literal(const int32_t* X, int64_t N, int P, const int32_t* z0, int nsamples,
+                             int K, double alpha, double beta, double gamma, double a, double b,
+                             int burnin, uint64_t seed, int32_t* z_out, double* theta_out,
+                             double* alpha_out);
+int oracle_collapsed_run(const int32_t* X, int64_t N, int P, const int32_t* z0, int nsamples, int K,
+                         double alpha, double beta, double gamma, double a, double b, int burnin,
+                         int64_t batch, uint64_t seed, int32_t* z_out, double* theta_out,
+                         double* alpha_out);
+int oracle_dp_literal(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta,
+                      double gamma, double a, double b, int burnin, int maxK, uint64_t seed,
+                      int32_t* z_out, double* theta_out, double* alpha_out);
+int oracle_dp_run(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta,
+                  double gamma, double a, double b, int burnin, int maxK, int64_t batch,
+                  uint64_t seed, int32_t* z_out, double* theta_out, double* alpha_out);
+int oracle_sb_literal(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                      int nsamples, int maxK, double alpha, double beta, double gamma, double a,
+                      double b, int burnin, uint64_t seed, double* pi_out, int32_t* z_out,
+                      double* theta_out, double* alpha_out);
+int oracle_sb_run(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                  int nsamples, int maxK, double alpha, double beta, double gamma, double a, double b,
+                  int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
+                  double* alpha_out);
+
+/* ---- CPU baseline timing: `nthreads` independent chains (seed+t), one per thread,
+ * each running `sweeps` sweeps of the *_run form; returns wall seconds (sweep loop only,
+ * set-up excluded), or a negative value on error.  sampler: 0 collapsed, 1 dp, 2 sb. ---- */
+double oracle_time_sweeps(int sampler, const int32_t* X, int64_t N, int P, int K, int sweeps,
+                          int64_t batch, uint64_t seed, int nthreads);
+
+const char* oracle_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+"""The oracle's two restatements of each sampler against each other, the returned
+object shapes (collapsed_gibbs.cpp:229-243, collapsed_gibbs_dp.cpp:285-299,
+stickbreaking.cpp:238-254) and statistical recovery of the bundled datasets'
+documented generating parameters (R/bmm-mcmc.R:13-17,31-35,46-50)."""
+import numpy as np
+import pytest
+
+from util import load_dataset, proportions, synth
+
+
+def _z0(N, K, seed):
+    return np.random.default_rng(seed).integers(1, K + 1, N).astype(np.int32)
+
+
+def test_collapsed_literal_equals_suffstat_batch1(oracle):
+    X = load_dataset("K2_N100_P5")
+    z0 = _z0(100, 2, 5)
+    a = oracle.collapsed(X, z0, 60, 2, 0.0, 0.5, 0.5, 1, 1, 6, seed=123, literal=True)
+    b = oracle.collapsed(X, z0, 60, 2, 0.0, 0.5, 0.5, 1, 1, 6, seed=123, batch=1)
+    assert a["z"].shape == (54, 100) and a["theta"].shape == (2, 5, 54) and a["alpha"].shape == (54, 1)
+    assert np.array_equal(a["z"], b["z"])
+    np.testing.assert_allclose(a["theta"], b["theta"], rtol=0, atol=0)
+    np.testing.assert_array_equal(a["alpha"], b["alpha"])
+
+
+def test_collapsed_fixed_alpha_and_burnin0_rows(oracle):
+    X = load_dataset("K3_N1000_P5")[::10]
+    z0 = _z0(100, 3, 1)
+    r = oracle.collapsed(X, z0, 5, 3, 2.5, 0.5, 0.5, 1, 1, 0, seed=9, batch=1)
+    assert np.array_equal(r["z"][0], z0)          # row 0 is the initial allocation (:46)
+    assert np.isnan(r["theta"][:, :, 0]).all()    # slice 0 never written
+    assert (r["alpha"] == 2.5).all()              # alpha != 0 -> fixed (:50-54)
+    assert r["z"].min() >= 1 and r["z"].max() <= 3
+
+
+def test_dp_literal_equals_suffstat_batch1(oracle):
+    X = load_dataset("K2_N100_P5")
+    a = oracle.dp(X, 40, 0.0, 0.5, 0.5, 1, 1, 4, 30, seed=77, literal=True)
+    b = oracle.dp(X, 40, 0.0, 0.5, 0.5, 1, 1, 4, 30, seed=77, batch=1)
+    assert a["z"].shape == (36, 100) and a["theta"].shape == (30, 5, 36)
+    assert np.array_equal(a["z"], b["z"])
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    np.testing.assert_array_equal(a["alpha"], b["alpha"])
+
+
+def test_dp_truncation_keeps_labels_below_maxK(oracle):
+    # tiny maxK forces the truncation branch (collapsed_gibbs_dp.cpp:218-230)
+    X = load_dataset("K3_N1000_P5")[::5]
+    for lit in (True, False):
+        r = oracle.dp(X, 12, 5.0, 0.5, 0.5, 1, 1, 2, 3, seed=4, literal=lit, batch=1)
+        assert r["z"].min() >= 1 and r["z"].max() <= 3
+        used = [len(np.unique(r["z"][s])) for s in range(r["z"].shape[0])]
+        assert max(used) <= 2  # K never exceeds maxK-1
+    a = oracle.dp(X, 12, 5.0, 0.5, 0.5, 1, 1, 2, 3, seed=4, literal=True)
+    b = oracle.dp(X, 12, 5.0, 0.5, 0.5, 1, 1, 2, 3, seed=4, batch=1)
+    assert np.array_equal(a["z"], b["z"])
+
+
+def test_dp_rejects_asymmetric_prior(oracle):
+    X = load_dataset("K2_N100_P5")
+    with pytest.raises(RuntimeError, match="non-symmetric"):
+        oracle.dp(X, 5, 1.0, 0.5, 0.7, 1, 1, 1, 30, seed=1)
+
+
+def test_sb_literal_equals_table_form(oracle):
+    X = load_dataset("K2_N100_P5")
+    rng = np.random.default_rng(3)
+    maxK = 6
+    pi0 = np.exp(rng.random(maxK)); pi0 /= pi0.sum()
+    th0 = rng.random((maxK, 5))
+    a = oracle.stickbreaking(X, pi0, th0, 50, maxK, 0.0, 0.5, 0.5, 1, 1, 5, seed=31, literal=True)
+    b = oracle.stickbreaking(X, pi0, th0, 50, maxK, 0.0, 0.5, 0.5, 1, 1, 5, seed=31)
+    assert a["pi"].shape == (45, maxK) and a["theta"].shape == (maxK, 5, 45) and a["z"].shape == (45, 100)
+    assert np.array_equal(a["z"], b["z"])
+    np.testing.assert_array_equal(a["pi"], b["pi"])
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    np.testing.assert_allclose(a["pi"].sum(axis=1), 1.0, atol=1e-12)
+
+
+def test_batched_collapsed_is_deterministic_and_differs_from_batch1(oracle):
+    X, _, _, _ = synth(2000, 12, 3, 18)
+    z0 = _z0(2000, 3, 2)
+    a = oracle.collapsed(X, z0, 8, 3, 1.0, 0.5, 0.5, 1, 1, 1, seed=5, batch=256)
+    b = oracle.collapsed(X, z0, 8, 3, 1.0, 0.5, 0.5, 1, 1, 1, seed=5, batch=256)
+    c = oracle.collapsed(X, z0, 8, 3, 1.0, 0.5, 0.5, 1, 1, 1, seed=5, batch=1)
+    assert np.array_equal(a["z"], b["z"])
+    assert not np.array_equal(a["z"], c["z"])
+
+
+@pytest.mark.parametrize("name,K,truth,tol", [("K2_N100_P5", 2, [0.7, 0.3], 0.05),
+                                               ("K2_N1000_P5", 2, [0.7, 0.3], 0.03),
+                                               ("K3_N1000_P5", 3, [0.6, 0.2, 0.2], 0.03)])
+def test_collapsed_recovers_mixing_proportions(oracle, name, K, truth, tol):
+    X = load_dataset(name)
+    N = X.shape[0]
+    batch = 1 if N <= 100 else 64
+    r = oracle.collapsed(X, _z0(N, K, 11), 400, K, 0.0, 0.5, 0.5, 1, 1, 100, seed=2024, batch=batch)
+    p = proportions(r["z"], K)
+    # the dominant component is pinned at SURVEY's tolerance; on K3 the two 0.2 components
+    # overlap (P = 5) and the exact batch-1 posterior mean itself is ~(0.60, 0.245, 0.155)
+    assert abs(p[0] - truth[0]) < tol
+    np.testing.assert_allclose(p, truth, atol=2 * tol)
+
+
+def test_sb_and_dp_recover_two_clusters(oracle):
+    X = load_dataset("K2_N1000_P5")
+    rng = np.random.default_rng(8)
+    maxK = 10
+    pi0 = np.exp(rng.random(maxK)); pi0 /= pi0.sum()
+    r = oracle.stickbreaking(X, pi0, rng.random((maxK, 5)), 400, maxK, 0.0, 0.5, 0.5, 1, 1, 150, seed=6)
+    p = proportions(r["z"], maxK)
+    assert abs(p[0] - 0.7) < 0.06 and abs(p[1] - 0.3) < 0.06
+    r = oracle.dp(X, 200, 0.0, 0.5, 0.5, 1, 1, 80, 30, seed=6, batch=50)
+    p = proportions(r["z"], 30)
+    assert abs(p[0] - 0.7) < 0.06 and abs(p[1] - 0.3) < 0.06
+
+
+def test_time_sweeps_runs_threads(oracle):
+    X, _, _, _ = synth(4000, 10, 3, 18)
+    t = oracle.time_sweeps("collapsed", X, 3, 3, 512, 1, 2)
+    assert 0 < t < 30
