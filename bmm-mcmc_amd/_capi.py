@@ -1,0 +1,77 @@
+"""ctypes binding of include/bmm_mcmc.h.  There is no fallback: if the HIP library is
+missing or no GPU is visible, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+
+SAMPLER_COLLAPSED, SAMPLER_DP, SAMPLER_SB = 0, 1, 2
+NA_INTEGER = -2147483648
+
+# every symbol include/bmm_mcmc.h declares
+SYMBOLS = [
+    "bmm_last_error", "bmm_spec_group_width", "bmm_default_batch", "bmm_collapsed_run", "bmm_dp_run",
+    "bmm_sb_run", "bmm_chain_create", "bmm_chain_destroy", "bmm_chain_set_data_host",
+    "bmm_chain_set_data_device", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
+    "bmm_chain_sweeps", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
+    "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",
+    "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_device_math", "bmm_device_variates",
+    "bmm_device_count",
+]
+
+
+class BmmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). This package has no CPU fallback.")
+        L = C.CDLL(path)
+        L.bmm_last_error.restype = C.c_char_p
+        L.bmm_default_batch.restype = C.c_int64
+        L.bmm_default_batch.argtypes = [C.c_int, C.c_int64]
+        L.bmm_chain_destroy.restype = None
+        L.bmm_chain_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise BmmError(rc, lib().bmm_last_error().decode())
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().bmm_device_count(C.byref(n))
+    return n.value
+
+
+def as_x(data):
+    """N x P integer matrix in R's layout (column-major int32); values must be 0/1."""
+    X = np.asarray(data)
+    if X.ndim != 2:
+        raise ValueError("data must be a matrix with observations in rows")
+    if X.dtype.kind == "f":
+        if not np.all(X == np.round(X)):
+            raise ValueError("data must be integer valued")
+    X = np.asfortranarray(X, dtype=np.int32)
+    if X.size and (X.min() < 0 or X.max() > 1):
+        raise ValueError("data must be binary (0/1)")
+    return X

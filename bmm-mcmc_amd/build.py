@@ -1,0 +1,40 @@
+"""Build recipe for the HIP library (gfx950 only).  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "chain.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(HERE, "csrc", "bmm_spec.h"),
+        os.path.join(os.path.dirname(HERE), "include", "bmm_mcmc.h")]
+LIB = os.path.join(HERE, "lib", "libbmmmcmc_hip.so")
+
+# -ffp-contract=off: the spec arithmetic (csrc/bmm_spec.h) fuses only where it says fma_
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return exe
+
+
+def stale():
+    return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,621 @@
+// chain.hip -- host driver and C ABI (include/bmm_mcmc.h) of the allocation path.
+//
+// One bmm_chain = one MCMC chain resident on one GPU: the data matrix, the label
+// rows, the integer sufficient statistics, the table image and every trace live in
+// HBM; the host only enqueues kernels on the chain's stream.  The sweep loop mirrors
+// the reference's (collapsed_gibbs.cpp:84-225, collapsed_gibbs_dp.cpp:98-283,
+// stickbreaking.cpp:66-236) with the per-observation loop replaced by batches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bmm_mcmc.h"
+#include "kernels.hip.h"
+
+using namespace bmm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return set_err(BMM_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                           __FILE__, __LINE__);                                                \
+    } while (0)
+
+// accumulator counts the resample kernel is instantiated for
+const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+constexpr int kThreadsSmall = 1024;  // KT <= 24: <= 128 VGPRs per lane
+constexpr int kThreadsLarge = 512;
+
+int pick_kt(int cats) {
+    for (int kt : kKT)
+        if (kt >= cats) return kt;
+    return -1;
+}
+int threads_for(int kt) { return kt <= 24 ? kThreadsSmall : kThreadsLarge; }
+
+typedef void (*resample_fn)(ChainParams, ResampleArgs);
+resample_fn resample_kernel(int kt) {
+    switch (kt) {
+        case 4: return k_resample<4, kThreadsSmall>;
+        case 8: return k_resample<8, kThreadsSmall>;
+        case 12: return k_resample<12, kThreadsSmall>;
+        case 16: return k_resample<16, kThreadsSmall>;
+        case 20: return k_resample<20, kThreadsSmall>;
+        case 24: return k_resample<24, kThreadsSmall>;
+        case 28: return k_resample<28, kThreadsLarge>;
+        case 32: return k_resample<32, kThreadsLarge>;
+        case 40: return k_resample<40, kThreadsLarge>;
+        case 48: return k_resample<48, kThreadsLarge>;
+        case 56: return k_resample<56, kThreadsLarge>;
+        case 64: return k_resample<64, kThreadsLarge>;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+struct bmm_chain {
+    ChainParams p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t batch = 1;
+    double alpha0 = 1.0;
+    int NT = 0, grid_max = 0;
+    size_t lds_bytes = 0;
+    resample_fn fn = nullptr;
+
+    const int32_t* dX = nullptr;
+    int32_t* dX_owned = nullptr;
+    int32_t* dZ[2] = {nullptr, nullptr};
+    int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
+    double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
+    bool have_data = false, have_init = false, started = false;
+    int sweep = 0;  // sweeps completed (= index j of the last one)
+
+    // trace of the *_run entry points
+    int burnin = 0, S = 0;
+    int32_t* dTrace = nullptr;  // [S][N], 0-based
+    double *dThetaTrace = nullptr, *dAlphaTrace = nullptr, *dPiTrace = nullptr;
+
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_n = 0;
+};
+
+namespace {
+
+int64_t default_batch(int sampler, int64_t N) {
+    if (sampler == BMM_SAMPLER_SB) return N;
+    // about eight batches per sweep, never more than 2^20 observations per batch
+    int64_t b = N / 8;
+    if (b < 1) b = 1;
+    if (b > (1 << 20)) b = 1 << 20;
+    return b;
+}
+
+TableLayout layout_of(const bmm_chain* c) {
+    return TableLayout{c->p.G, c->p.KT, c->p.mode != MODE_SB ? 1 : 0};
+}
+
+int32_t* label_row(bmm_chain* c, int j) {
+    if (c->dTrace && j >= c->burnin) return c->dTrace + (size_t)(j - c->burnin) * c->p.N;
+    return c->dZ[j & 1];
+}
+
+int chain_alloc(bmm_chain* c) {
+    const ChainParams& p = c->p;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nz = (size_t)p.N * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&c->dZ[0], nz));
+    HIP_TRY(hipMalloc(&c->dZ[1], nz));
+    const size_t ns = (size_t)p.K * p.P * sizeof(int32_t), nn = (size_t)p.K * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&c->dNk, nn));
+    HIP_TRY(hipMalloc(&c->dDNk, nn));
+    HIP_TRY(hipMalloc(&c->dS, ns));
+    HIP_TRY(hipMalloc(&c->dDS, ns));
+    HIP_TRY(hipMalloc(&c->dAlpha, sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dTab, (size_t)layout_of(c).doubles() * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dPi, (size_t)p.K * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dTheta, (size_t)p.K * p.P * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->dNk, 0, nn, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dDNk, 0, nn, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dS, 0, ns, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dDS, 0, ns, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dTab, 0, (size_t)layout_of(c).doubles() * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz, c->stream));  // -1 = unassigned
+    HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMM_OK;
+}
+
+int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t lo, int64_t hi,
+                    uint32_t sweep, int assign_only) {
+    ResampleArgs a{};
+    a.X = c->dX; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
+    a.lo = lo; a.hi = hi; a.sweep = sweep; a.assign_only = assign_only;
+    const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
+    const int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->prof && !assign_only) {
+        if (c->ev_used + 2 > c->ev.size()) {
+            hipEvent_t a0, a1;
+            HIP_TRY(hipEventCreate(&a0));
+            HIP_TRY(hipEventCreate(&a1));
+            c->ev.push_back(a0); c->ev.push_back(a1);
+        }
+        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    hipLaunchKernelGGL(c->fn, dim3(grid), dim3(c->NT), c->lds_bytes, c->stream, c->p, a);
+    HIP_TRY(hipGetLastError());
+    if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    return BMM_OK;
+}
+
+int launch_count_tables(bmm_chain* c) {
+    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(128), 0, c->stream, c->p, c->dNk, c->dS,
+                       c->dDNk, c->dDS, c->dAlpha, c->dTab);
+    HIP_TRY(hipGetLastError());
+    return BMM_OK;
+}
+
+// one sweep (index j >= 1) enqueued on the stream
+int enqueue_sweep(bmm_chain* c, int j) {
+    const ChainParams& p = c->p;
+    const int32_t* zin = (p.mode != MODE_COLLAPSED && j == 1) ? nullptr : label_row(c, j - 1);
+    int32_t* zout = label_row(c, j);
+    const bool rec = c->dTrace && j >= c->burnin;
+    const int s = j - c->burnin;
+    double* th_tr = rec ? c->dThetaTrace + (size_t)s * p.K * p.P : nullptr;
+    double* al_tr = rec ? c->dAlphaTrace + s : nullptr;
+    if (p.mode == MODE_SB) {
+        int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
+                           c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
+                           al_tr);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
+                           c->dPi, c->dTheta, 1, (uint32_t)j, th_tr, c->dTab);
+        HIP_TRY(hipGetLastError());
+        return BMM_OK;
+    }
+    int64_t lo = 0;
+    while (lo < p.N) {
+        int64_t len = c->batch;
+        if (p.mode == MODE_DP && j == 1) {  // seat the first sweep 1,1,2,4,... at a time
+            const int64_t dbl = lo < 1 ? 1 : lo;
+            if (dbl < len) len = dbl;
+        }
+        const int64_t hi = lo + len > p.N ? p.N : lo + len;
+        int rc = launch_count_tables(c);
+        if (rc) return rc;
+        rc = launch_resample(c, zin, zout, lo, hi, (uint32_t)j, 0);
+        if (rc) return rc;
+        lo = hi;
+    }
+    hipLaunchKernelGGL(k_count_sweep_end, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
+                       c->dDS, c->dAlpha, (uint32_t)j, th_tr, al_tr);
+    HIP_TRY(hipGetLastError());
+    return BMM_OK;
+}
+
+// things that must be in place before the first sweep
+int chain_start(bmm_chain* c) {
+    const ChainParams& p = c->p;
+    if (!c->have_data) return set_err(BMM_E_STATE, "data matrix not set");
+    if (p.mode != MODE_DP && !c->have_init)
+        return set_err(BMM_E_STATE, p.mode == MODE_COLLAPSED ? "initial labels not set"
+                                                             : "initial pi/theta not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (p.mode == MODE_COLLAPSED) {
+        // statistics of the initial allocation (collapsed_gibbs.cpp:60-63)
+        int32_t* row0 = label_row(c, 0);
+        if (row0 != c->dZ[0])
+            HIP_TRY(hipMemcpyAsync(row0, c->dZ[0], (size_t)p.N * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                   c->stream));
+        int rc = launch_resample(c, row0, row0, 0, p.N, 0, 1);
+        if (rc) return rc;
+    } else if (p.mode == MODE_SB) {
+        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
+                           c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab);
+        HIP_TRY(hipGetLastError());
+    }
+    c->started = true;
+    return BMM_OK;
+}
+
+int check_common(int64_t N, int P, int K, double beta, double gamma) {
+    if (N < 1) return set_err(BMM_E_ARG, "N must be >= 1");
+    if (P < 1) return set_err(BMM_E_ARG, "P must be >= 1");
+    if (K < 1) return set_err(BMM_E_ARG, "K must be >= 1");
+    if (!(beta > 0.0) || !(gamma > 0.0)) return set_err(BMM_E_ARG, "beta and gamma must be > 0");
+    if (P > kMaxP) return set_err(BMM_E_UNSUPPORTED, "P = %d exceeds %d features", P, kMaxP);
+    return BMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bmm_last_error(void) { return g_err; }
+int bmm_spec_group_width(void) { return kGroupW; }
+int64_t bmm_default_batch(int sampler, int64_t N) { return default_batch(sampler, N); }
+
+int bmm_device_count(int* n) {
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *n = 0; return set_err(BMM_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = k;
+    return BMM_OK;
+}
+
+int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, double alpha, double beta,
+                     double gamma, double a, double b, int64_t batch, uint64_t seed, int device) {
+    if (!out) return set_err(BMM_E_ARG, "out is null");
+    *out = nullptr;
+    if (sampler < 0 || sampler > 2) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
+    int rc = check_common(N, P, K, beta, gamma);
+    if (rc) return rc;
+    if (sampler == BMM_SAMPLER_DP && beta != gamma)  // collapsed_gibbs_dp.cpp:48-50
+        return set_err(BMM_E_ARG, "Error: sampler currently not implemented for non-symmetric priors on beta and gamma");
+    if (sampler == BMM_SAMPLER_DP && K < 2) return set_err(BMM_E_ARG, "maxK must be >= 2");
+    if (alpha < 0.0) return set_err(BMM_E_ARG, "alpha must be >= 0 (0 = sample it)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(BMM_E_NODEVICE, "no HIP device visible; this path has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_err(BMM_E_ARG, "device %d out of range (have %d)", device, ndev);
+
+    bmm_chain* c = new (std::nothrow) bmm_chain();
+    if (!c) return set_err(BMM_E_ARG, "out of host memory");
+    ChainParams& p = c->p;
+    p.mode = sampler; p.N = N; p.P = P; p.G = (P + kGroupW - 1) / kGroupW; p.K = K;
+    p.Kc = sampler == BMM_SAMPLER_DP ? K + 1 : K;
+    p.KT = pick_kt(p.Kc);
+    p.beta = beta; p.gamma = gamma; p.a = a; p.b = b; p.seed = seed;
+    p.sample_alpha = alpha == 0.0;  // collapsed_gibbs.cpp:50-54
+    c->alpha0 = p.sample_alpha ? 1.0 : alpha;
+    c->device = device;
+    c->batch = batch <= 0 ? default_batch(sampler, N) : (batch > N ? N : batch);
+    if (sampler == BMM_SAMPLER_SB) c->batch = N;
+    if (p.KT < 0) {
+        delete c;
+        return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build tabulates on chip", p.Kc, kMaxCats);
+    }
+    c->NT = threads_for(p.KT);
+    c->fn = resample_kernel(p.KT);
+    c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + ((size_t)K * P + K) * sizeof(int32_t);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
+    const size_t lds_cap = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 65536;
+    const size_t lds_max = lds_cap > 163840 ? lds_cap : 163840;  // gfx950: 160 KiB per workgroup
+    if (c->lds_bytes > lds_max) {
+        const size_t need = c->lds_bytes;
+        delete c;
+        return set_err(BMM_E_UNSUPPORTED, "K = %d, P = %d need %zu bytes of LDS tables; the CU has %zu", K, P, need, lds_max);
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    int per_cu = 0;
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c->fn), c->NT, c->lds_bytes);
+    if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
+    if (per_cu < 1) per_cu = 1;
+    c->grid_max = per_cu * prop.multiProcessorCount;
+    rc = chain_alloc(c);
+    if (rc) { bmm_chain_destroy(c); return rc; }
+    *out = c;
+    return BMM_OK;
+}
+
+void bmm_chain_destroy(bmm_chain* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
+                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
+    if (!c || !X) return set_err(BMM_E_ARG, "null argument");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->p.N * c->p.P * sizeof(int32_t);
+    if (!c->dX_owned) HIP_TRY(hipMalloc(&c->dX_owned, bytes));
+    HIP_TRY(hipMemcpyAsync(c->dX_owned, X, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dX = c->dX_owned;
+    c->have_data = true;
+    return BMM_OK;
+}
+
+int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
+    if (!c || !dX) return set_err(BMM_E_ARG, "null argument");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dX) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return set_err(BMM_E_ARG, "dX is not a device pointer");
+    }
+    if (at.device != c->device) return set_err(BMM_E_ARG, "dX lives on device %d, chain on %d", at.device, c->device);
+    c->dX = static_cast<const int32_t*>(dX);
+    c->have_data = true;
+    return BMM_OK;
+}
+
+int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1) {
+    if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
+    if (c->p.mode != MODE_COLLAPSED) return set_err(BMM_E_STATE, "only the finite collapsed sampler takes initial labels");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    std::vector<int32_t> z0((size_t)c->p.N);
+    for (int64_t i = 0; i < c->p.N; ++i) {
+        if (z1[i] < 1 || z1[i] > c->p.K) return set_err(BMM_E_ARG, "initialK[%lld] = %d outside 1..%d", (long long)i, z1[i], c->p.K);
+        z0[(size_t)i] = z1[i] - 1;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->dZ[0], z0.data(), z0.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_init = true;
+    return BMM_OK;
+}
+
+int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* theta) {
+    if (!c || !pi || !theta) return set_err(BMM_E_ARG, "null argument");
+    if (c->p.mode != MODE_SB) return set_err(BMM_E_STATE, "only the stick-breaking sampler takes initial pi/theta");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->dPi, pi, (size_t)c->p.K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dTheta, theta, (size_t)c->p.K * c->p.P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_init = true;
+    return BMM_OK;
+}
+
+int bmm_chain_sweeps(bmm_chain* c, int n) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (n < 0) return set_err(BMM_E_ARG, "n must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->started) {
+        int rc = chain_start(c);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < n; ++t) {
+        int rc = enqueue_sweep(c, c->sweep + 1);
+        if (rc) return rc;
+        c->sweep++;
+    }
+    return BMM_OK;
+}
+
+int bmm_chain_sync(bmm_chain* c) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->prof_ms += ms;
+        c->prof_n++;
+    }
+    c->ev_used = 0;
+    return BMM_OK;
+}
+
+int bmm_chain_sweep_index(const bmm_chain* c) { return c ? c->sweep : -1; }
+
+int bmm_chain_get_labels(bmm_chain* c, int32_t* z1) {
+    if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(z1, label_row(c, c->sweep), (size_t)c->p.N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < c->p.N; ++i) z1[i] = z1[i] < 0 ? BMM_NA_INTEGER : z1[i] + 1;
+    return BMM_OK;
+}
+
+int bmm_chain_get_counts(bmm_chain* c, int32_t* Nk, int32_t* S) {
+    if (!c || !Nk || !S) return set_err(BMM_E_ARG, "null argument");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    const size_t K = (size_t)c->p.K, KP = K * c->p.P;
+    std::vector<int32_t> d(KP > K ? KP : K);
+    HIP_TRY(hipMemcpy(Nk, c->dNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d.data(), c->dDNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < K; ++k) Nk[k] += d[k];
+    HIP_TRY(hipMemcpy(S, c->dS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d.data(), c->dDS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < KP; ++q) S[q] += d[q];
+    return BMM_OK;
+}
+
+int bmm_chain_get_alpha(bmm_chain* c, double* alpha) {
+    if (!c || !alpha) return set_err(BMM_E_ARG, "null argument");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(alpha, c->dAlpha, sizeof(double), hipMemcpyDeviceToHost));
+    return BMM_OK;
+}
+
+int bmm_chain_get_params(bmm_chain* c, double* pi, double* theta) {
+    if (!c || !pi || !theta) return set_err(BMM_E_ARG, "null argument");
+    if (c->p.mode != MODE_SB) return set_err(BMM_E_STATE, "only the stick-breaking sampler carries pi/theta");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(pi, c->dPi, (size_t)c->p.K * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(theta, c->dTheta, (size_t)c->p.K * c->p.P * sizeof(double), hipMemcpyDeviceToHost));
+    return BMM_OK;
+}
+
+int bmm_chain_profile(bmm_chain* c, int enable) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    c->prof = enable != 0;
+    c->prof_ms = 0.0;
+    c->prof_n = 0;
+    return BMM_OK;
+}
+
+int bmm_chain_profile_read(bmm_chain* c, double* resample_ms, int64_t* resample_launches) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    int rc = bmm_chain_sync(c);
+    if (rc) return rc;
+    if (resample_ms) *resample_ms = c->prof_ms;
+    if (resample_launches) *resample_launches = c->prof_n;
+    return BMM_OK;
+}
+
+int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int* grid_max) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (lds_bytes) *lds_bytes = (int)c->lds_bytes;
+    if (threads) *threads = c->NT;
+    if (grid_max) *grid_max = c->grid_max;
+    return BMM_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ *_run entry points
+namespace {
+
+int run_chain(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0, const double* pi0,
+              const double* theta0, int nsamples, int K, double alpha, double beta, double gamma, double a,
+              double b, int burnin, int64_t batch, uint64_t seed, int device, double* pi_out,
+              int32_t* z_out, double* theta_out, double* alpha_out) {
+    if (!X || !z_out || !theta_out || !alpha_out) return set_err(BMM_E_ARG, "null buffer");
+    if (nsamples < 1) return set_err(BMM_E_ARG, "nsamples must be >= 1");
+    if (burnin < 0 || burnin >= nsamples) return set_err(BMM_E_ARG, "burnin must be in [0, nsamples)");
+    bmm_chain* c = nullptr;
+    int rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
+    if (rc) return rc;
+    struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
+    const int S = nsamples - burnin;
+    c->burnin = burnin; c->S = S;
+    HIP_TRY(hipMalloc(&c->dTrace, (size_t)S * N * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->dThetaTrace, (size_t)S * K * P * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dAlphaTrace, (size_t)S * sizeof(double)));
+    if (sampler == BMM_SAMPLER_SB) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
+    rc = bmm_chain_set_data_host(c, X);
+    if (rc) return rc;
+    if (sampler == BMM_SAMPLER_COLLAPSED) rc = bmm_chain_set_initial_labels(c, z0);
+    if (sampler == BMM_SAMPLER_SB) rc = bmm_chain_set_initial_params(c, pi0, theta0);
+    if (rc) return rc;
+    if (burnin == 0) {
+        // trace row 0 (DESIGN.md "Quirks"): labels = initial allocation or unassigned (-1 -> NA),
+        // theta = NaN (collapsed, never written), 0 (dp, zero-filled) or the initial theta (sb)
+        std::vector<double> t0((size_t)K * P, sampler == BMM_SAMPLER_DP ? 0.0 : std::nan(""));
+        if (sampler == BMM_SAMPLER_SB) std::memcpy(t0.data(), theta0, t0.size() * sizeof(double));
+        HIP_TRY(hipMemcpy(c->dThetaTrace, t0.data(), t0.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->dAlphaTrace, &c->alpha0, sizeof(double), hipMemcpyHostToDevice));
+        if (sampler == BMM_SAMPLER_SB)
+            HIP_TRY(hipMemcpy2D(c->dPiTrace, (size_t)S * sizeof(double), pi0, sizeof(double), sizeof(double), K, hipMemcpyHostToDevice));
+        if (sampler != BMM_SAMPLER_COLLAPSED) HIP_TRY(hipMemset(c->dTrace, 0xff, (size_t)N * sizeof(int32_t)));
+    }
+    rc = bmm_chain_sweeps(c, nsamples - 1);
+    if (rc) return rc;
+    // labels: [S][N] 0-based -> S x N column-major 1-based, on the device, then one copy out
+    int32_t* dOut = nullptr;
+    HIP_TRY(hipMalloc(&dOut, (size_t)S * N * sizeof(int32_t)));
+    struct Free { void* p; ~Free() { (void)hipFree(p); } } fo{dOut};
+    hipLaunchKernelGGL(k_trace_to_r, dim3((unsigned)((N + 31) / 32), (unsigned)((S + 31) / 32)), dim3(256), 0,
+                       c->stream, c->dTrace, N, S, dOut);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(z_out, dOut, (size_t)S * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(theta_out, c->dThetaTrace, (size_t)S * K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(alpha_out, c->dAlphaTrace, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (sampler == BMM_SAMPLER_SB)
+        HIP_TRY(hipMemcpyAsync(pi_out, c->dPiTrace, (size_t)S * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmm_collapsed_run(const int32_t* X, int64_t N, int P, const int32_t* initialK, int nsamples, int K,
+                      double alpha, double beta, double gamma, double a, double b, int burnin,
+                      int64_t batch, uint64_t seed, int device, int32_t* z_out, double* theta_out,
+                      double* alpha_out) {
+    if (!initialK) return set_err(BMM_E_ARG, "initialK is null");
+    return run_chain(BMM_SAMPLER_COLLAPSED, X, N, P, initialK, nullptr, nullptr, nsamples, K, alpha, beta,
+                     gamma, a, b, burnin, batch, seed, device, nullptr, z_out, theta_out, alpha_out);
+}
+
+int bmm_dp_run(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta, double gamma,
+               double a, double b, int burnin, int maxK, int64_t batch, uint64_t seed, int device,
+               int32_t* z_out, double* theta_out, double* alpha_out) {
+    return run_chain(BMM_SAMPLER_DP, X, N, P, nullptr, nullptr, nullptr, nsamples, maxK, alpha, beta, gamma,
+                     a, b, burnin, batch, seed, device, nullptr, z_out, theta_out, alpha_out);
+}
+
+int bmm_sb_run(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
+               int nsamples, int maxK, double alpha, double beta, double gamma, double a, double b,
+               int burnin, uint64_t seed, int device, double* pi_out, int32_t* z_out, double* theta_out,
+               double* alpha_out) {
+    if (!initialPi || !initialTheta || !pi_out) return set_err(BMM_E_ARG, "null buffer");
+    return run_chain(BMM_SAMPLER_SB, X, N, P, nullptr, initialPi, initialTheta, nsamples, maxK, alpha, beta,
+                     gamma, a, b, burnin, 0, seed, device, pi_out, z_out, theta_out, alpha_out);
+}
+
+int bmm_device_math(int device, int op, const double* in, const double* in2, double* out, int64_t n) {
+    if (!in || !out || n < 0 || op < 0 || op > 3) return set_err(BMM_E_ARG, "bad argument");
+    if (op == 2 && !in2) return set_err(BMM_E_ARG, "division needs in2");
+    HIP_TRY(hipSetDevice(device));
+    double *di = nullptr, *di2 = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&di, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&dout, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(di, in, n * sizeof(double), hipMemcpyHostToDevice));
+    if (in2) {
+        HIP_TRY(hipMalloc(&di2, n * sizeof(double)));
+        HIP_TRY(hipMemcpy(di2, in2, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, di, di2, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(di); (void)hipFree(dout);
+    if (di2) (void)hipFree(di2);
+    return BMM_OK;
+}
+
+int bmm_device_variates(int device, int kind, double p, double q, uint64_t seed, uint32_t sweep, double* out,
+                        int64_t n) {
+    if (!out || n < 0 || kind < 0 || kind > 2) return set_err(BMM_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    double* dout = nullptr;
+    HIP_TRY(hipMalloc(&dout, n * sizeof(double)));
+    hipLaunchKernelGGL(k_test_variates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, kind, p, q, seed, sweep, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dout);
+    return BMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+// kernels.hip.h -- gfx950 kernels of the cluster-allocation path.
+//
+// One observation per lane (wave64).  The N x P data matrix is read in the layout R
+// hands over (int32, column-major): lane i reads X[i + d*N], so a wave reads 256
+// contiguous bytes per feature.  Features are packed to bits in registers as they
+// arrive; the per-cluster log-predictive is then K*ceil(P/4) LDS lookups into
+// 16-entry group tables (one ds_read_b64 + one v_add_f64 per cluster per 4 features)
+// instead of K*P multiply-adds.  All 16 entries of a group sit in one 128-byte run,
+// i.e. on 16 different bank pairs, so the per-lane-indexed read is conflict-free.
+// Sufficient-statistic changes are accumulated as integers in LDS (wave-cooperative:
+// one mover at a time, one feature per lane) and flushed with one global integer
+// atomic per touched cell per workgroup -- order-independent, hence deterministic.
+//
+// Reference lines realised here (all /root/reference/src):
+//   z | rest, finite K      collapsed_gibbs.cpp:86-182
+//   z | rest, CRP           collapsed_gibbs_dp.cpp:108-242
+//   z | pi, theta           stickbreaking.cpp:70-125, counts :164-186
+//   theta-hat               collapsed_gibbs.cpp:205-219, collapsed_gibbs_dp.cpp:266-281
+//   v, pi, theta draws      stickbreaking.cpp:187-229
+//   alpha                   utils.cpp:6-14
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bmm_spec.h"
+
+namespace bmm {
+
+constexpr int kMaxP = 128;      // 4 bit-words per observation
+constexpr int kMaxCats = 64;    // clusters (+ the DP's new-cluster option)
+
+enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2 };
+
+// Layout of the table image (identical in global memory and in LDS), in doubles:
+//   Tp  [G][KT][16]   group tables against the full statistics
+//   Tm  [G][KT][16]   ... with the scored observation's own contribution removed (not SB)
+//   Cp  [KT]          prior / weight term per category
+//   Cm  [KT]
+//   Nk  [KT] int32 (packed two per double slot)
+struct TableLayout {
+    int G, KT, has_minus;
+    __host__ __device__ int tp() const { return 0; }
+    __host__ __device__ int tm() const { return G * KT * kGroupM; }
+    __host__ __device__ int cp() const { return (has_minus ? 2 : 1) * G * KT * kGroupM; }
+    __host__ __device__ int cm() const { return cp() + KT; }
+    __host__ __device__ int nk() const { return cm() + KT; }           // KT ints = KT/2 doubles
+    __host__ __device__ int doubles() const { return nk() + (KT + 1) / 2 + ((KT + 1) / 2 & 1); }  // even
+};
+
+struct ChainParams {
+    int mode;           // MODE_*
+    int64_t N;
+    int P, G;
+    int K;              // labels (K or maxK)
+    int Kc;             // categories = K (+1 for DP)
+    int KT;             // Kc rounded up to the kernel's accumulator count
+    double beta, gamma, a, b;
+    int sample_alpha;
+    uint64_t seed;
+};
+
+// ---------------------------------------------------------------------------------
+// Table construction: one workgroup per category.  For the counting samplers it first
+// folds the pending integer deltas of its cluster into the statistics.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void write_group_tables(const double* e1, const double* e0, int P, int G,
+                                                   int KT, int k, double* T) {
+    for (int idx = threadIdx.x; idx < G * kGroupM; idx += blockDim.x) {
+        const int g = idx / kGroupM;
+        const unsigned m = idx % kGroupM;
+        T[(g * KT + k) * kGroupM + m] = group_entry(e1, e0, g, P, m);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
+                                                      int32_t* __restrict__ S,
+                                                      int32_t* __restrict__ dNk,
+                                                      int32_t* __restrict__ dS,
+                                                      const double* __restrict__ alpha_ptr,
+                                                      double* __restrict__ tab) {
+    __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP];
+    __shared__ int64_t n_sh;
+    const int k = blockIdx.x;
+    const TableLayout L{p.G, p.KT, 1};
+    const int P = p.P;
+    const double alpha = *alpha_ptr;
+    int64_t n = 0;
+    const bool is_label = k < p.K;
+    if (is_label) {
+        if (threadIdx.x == 0) {
+            const int32_t v = Nk[k] + dNk[k];
+            Nk[k] = v; dNk[k] = 0; n_sh = v;
+        }
+        __syncthreads();
+        n = n_sh;
+    }
+    const double bg = p.beta + p.gamma;
+    const double den_p = n > 0 ? log_(bg + (double)n) : 0.0;
+    const double den_m = n > 1 ? log_(bg + (double)(n - 1)) : 0.0;
+    for (int d = threadIdx.x; d < P; d += blockDim.x) {
+        double a1 = 0.0, a0 = 0.0, b1 = 0.0, b0 = 0.0;
+        if (is_label) {
+            const int32_t s = S[k * P + d] + dS[k * P + d];
+            S[k * P + d] = s; dS[k * P + d] = 0;
+            if (n > 0) {
+                a1 = term_x1(p.beta, s, den_p);
+                a0 = term_x0(p.gamma, n, s, den_p);
+            }
+            if (n > 1) {
+                b1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
+                b0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
+            }
+        }
+        e1[d] = a1; e0[d] = a0; m1[d] = b1; m0[d] = b0;
+    }
+    __syncthreads();
+    write_group_tables(e1, e0, P, p.G, p.KT, k, tab + L.tp());
+    write_group_tables(m1, m0, P, p.G, p.KT, k, tab + L.tm());
+    if (threadIdx.x == 0) {
+        double cp = neg_inf(), cm = neg_inf();
+        const double ldN = log_((double)(p.N - 1) + alpha);
+        if (is_label) {
+            if (p.mode == MODE_COLLAPSED) {
+                const double ak = div_(alpha, (double)p.K);
+                if (n > 0) cp = log_((double)n + ak) - ldN;
+                if (n > 1) cm = log_((double)(n - 1) + ak) - ldN;
+            } else {
+                if (n > 0) cp = log_((double)n) - ldN;
+                if (n > 1) cm = log_((double)(n - 1)) - ldN;
+            }
+        } else if (p.mode == MODE_DP && k == p.K) {
+            cp = (log_(alpha) - ldN) + (double)P * (log_(p.beta) - log_(bg));
+        }
+        tab[L.cp() + k] = cp;
+        tab[L.cm() + k] = cm;
+        reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
+    }
+}
+
+// Stick-breaking: theta_kd ~ Beta(beta + V_kd, gamma + c_k - V_kd) (stickbreaking.cpp:217-229),
+// unless draw == 0 (initial theta is used as given), then the tables of cluster k.
+__global__ __launch_bounds__(128) void k_sb_theta_tables(ChainParams p, const int32_t* __restrict__ Nk,
+                                                         const int32_t* __restrict__ S,
+                                                         const double* __restrict__ pi,
+                                                         double* __restrict__ theta, int draw,
+                                                         uint32_t sweep, double* __restrict__ theta_trace,
+                                                         double* __restrict__ tab) {
+    __shared__ double e1[kMaxP], e0[kMaxP];
+    const int k = blockIdx.x;
+    const TableLayout L{p.G, p.KT, 0};
+    const int P = p.P, K = p.K;
+    const bool is_label = k < K;
+    for (int d = threadIdx.x; d < P; d += blockDim.x) {
+        double a1 = 0.0, a0 = 0.0;
+        if (is_label) {
+            double th;
+            if (draw) {
+                const int32_t ck = Nk[k], V = S[k * P + d];
+                const uint32_t c0 = (uint32_t)(k * P + d);
+                Stream sa = make_stream(p.seed, c0, sweep, kStreamThetaA);
+                Stream sb = make_stream(p.seed, c0, sweep, kStreamThetaB);
+                th = rbeta_(p.beta + (double)V, (p.gamma + (double)ck) - (double)V, sa, sb);
+                theta[k + d * K] = th;
+            } else {
+                th = theta[k + d * K];
+            }
+            if (theta_trace) theta_trace[k + d * K] = th;
+            a1 = log_(th);
+            a0 = log_(1.0 - th);
+        }
+        e1[d] = a1; e0[d] = a0;
+    }
+    __syncthreads();
+    write_group_tables(e1, e0, P, p.G, p.KT, k, tab + L.tp());
+    if (threadIdx.x == 0) {
+        tab[L.cp() + k] = is_label ? log_(pi[k]) : neg_inf();
+        tab[L.cm() + k] = neg_inf();
+        reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
+    }
+}
+
+// Stick-breaking: fold deltas, v_k ~ Beta(1 + c_k, alpha + sum_{l>k} c_l), pi by stick
+// breaking, K_viable, alpha (stickbreaking.cpp:164-214, 233-235).  One workgroup.
+__global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __restrict__ Nk,
+                                                   int32_t* __restrict__ S, int32_t* __restrict__ dNk,
+                                                   int32_t* __restrict__ dS, double* __restrict__ alpha_ptr,
+                                                   double* __restrict__ pi, uint32_t sweep,
+                                                   double* __restrict__ pi_trace, int pi_stride,
+                                                   double* __restrict__ alpha_trace) {
+    __shared__ int32_t ck[kMaxCats];
+    __shared__ double v[kMaxCats];
+    const int K = p.K, P = p.P;
+    for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
+        S[idx] += dS[idx]; dS[idx] = 0;
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int32_t n = Nk[k] + dNk[k];
+        Nk[k] = n; dNk[k] = 0; ck[k] = n;
+    }
+    __syncthreads();
+    const double alpha_prev = *alpha_ptr;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int64_t prev = 0;
+        for (int l = k + 1; l < K; ++l) prev += ck[l];
+        Stream sa = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickA);
+        Stream sb = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickB);
+        v[k] = rbeta_(1.0 + (double)ck[k], alpha_prev + (double)prev, sa, sb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v[K - 1] = 1.0;
+        int viable = 0;
+        double cumprod = 1.0;
+        for (int k = 0; k < K; ++k) {
+            const double pk = k == 0 ? v[0] : cumprod * v[k];
+            if (pk > 0.01) ++viable;
+            cumprod = k == 0 ? 1.0 - v[0] : cumprod * (1.0 - v[k]);
+            pi[k] = pk;
+            if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
+        }
+        double alpha_new = alpha_prev;
+        if (p.sample_alpha) {
+            alpha_new = update_alpha_(alpha_prev, p.a, p.b, (double)p.N, viable, p.seed, sweep);
+            *alpha_ptr = alpha_new;
+        }
+        if (alpha_trace) *alpha_trace = alpha_new;
+    }
+}
+
+// Counting samplers, end of sweep: fold what the last batch left, theta-hat = S/Nk
+// (NaN for an empty cluster in the finite sampler, 0 for an unused DP label), alpha.
+__global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t* __restrict__ Nk,
+                                                         int32_t* __restrict__ S,
+                                                         int32_t* __restrict__ dNk,
+                                                         int32_t* __restrict__ dS,
+                                                         double* __restrict__ alpha_ptr, uint32_t sweep,
+                                                         double* __restrict__ theta_trace,
+                                                         double* __restrict__ alpha_trace) {
+    __shared__ int32_t nk[kMaxCats];
+    const int K = p.K, P = p.P;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int32_t n = Nk[k] + dNk[k];
+        Nk[k] = n; dNk[k] = 0; nk[k] = n;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
+        const int k = idx / P, d = idx % P;
+        const int32_t s = S[idx] + dS[idx];
+        S[idx] = s; dS[idx] = 0;
+        if (theta_trace) {
+            double t;
+            if (p.mode == MODE_DP && nk[k] == 0) t = 0.0;
+            else t = div_((double)s, (double)nk[k]);
+            theta_trace[k + d * K] = t;
+        }
+    }
+    if (threadIdx.x == 0) {
+        double al = *alpha_ptr;
+        if (p.sample_alpha) {
+            int Kc = K;
+            if (p.mode == MODE_DP) { Kc = 0; for (int k = 0; k < K; ++k) Kc += nk[k] > 0; }
+            al = update_alpha_(al, p.a, p.b, (double)p.N, Kc, p.seed, sweep);
+            *alpha_ptr = al;
+        }
+        if (alpha_trace) *alpha_trace = al;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The z-resample kernel.
+// ---------------------------------------------------------------------------------
+struct ResampleArgs {
+    const int32_t* X;
+    const int32_t* z_in;   // 0-based labels of the previous sweep, -1 = unassigned
+    int32_t* z_out;
+    const double* tab;     // table image (TableLayout)
+    int32_t* dNk;          // global delta accumulators
+    int32_t* dS;
+    int64_t lo, hi;        // batch [lo, hi)
+    uint32_t sweep;
+    int assign_only;       // 1: z_out = z_in, count everything as arriving (initial statistics)
+};
+
+template <int KT, int NT>
+__global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool has_minus = p.mode != MODE_SB;
+    const TableLayout L{p.G, KT, has_minus ? 1 : 0};
+    double* const lds = reinterpret_cast<double*>(smem);
+    const double* const Tp = lds + L.tp();
+    const double* const Tm = lds + L.tm();
+    const double* const Cp = lds + L.cp();
+    const double* const Cm = lds + L.cm();
+    const int32_t* const NkT = reinterpret_cast<const int32_t*>(lds + L.nk());
+    int32_t* const hist = reinterpret_cast<int32_t*>(lds + L.doubles());  // [K*P] then [K]
+    const int P = p.P, G = p.G, K = p.K;
+    const int nhist = K * P + K;
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    if (!a.assign_only) {
+        const double2* src = reinterpret_cast<const double2*>(a.tab);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < L.doubles() / 2; i += NT) dst[i] = src[i];
+    }
+    for (int i = tid; i < nhist; i += NT) hist[i] = 0;
+    __syncthreads();
+
+    // DP bookkeeping shared by the whole batch (collapsed_gibbs_dp.cpp:166-171,212-231)
+    int Kused = 0, new_label = -1;
+    if (p.mode == MODE_DP && !a.assign_only) {
+        for (int k = 0; k < K; ++k) {
+            if (NkT[k] > 0) ++Kused;
+            else if (new_label < 0) new_label = k;
+        }
+    }
+
+    const int64_t span = a.hi - a.lo;
+    const int64_t ntiles = (span + NT - 1) / NT;
+    const int nchunks = (P + 7) / 8;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = a.lo + tile * NT + tid;
+        const bool valid = i < a.hi;
+        const int64_t ic = valid ? i : a.hi - 1;
+        const int zo = a.z_in ? a.z_in[ic] : -1;
+        const int zoc = zo < 0 ? 0 : zo;
+        const int32_t* xcol = a.X + ic;
+
+        double acc[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[k] = 0.0;
+        double acc_own = 0.0;
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+
+        for (int c = 0; c < nchunks; ++c) {
+            // eight features: 8 coalesced dword loads in flight per lane
+            uint32_t byte = 0;
+            const int d0 = c * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int d = d0 + t < P ? d0 + t : P - 1;
+                const uint32_t v = (uint32_t)xcol[(int64_t)d * p.N];
+                byte |= (d0 + t < P ? (v & 1u) : 0u) << t;
+            }
+            const uint32_t shifted = byte << ((c & 3) * 8);
+            const int wd = c >> 2;
+            b0 |= wd == 0 ? shifted : 0u;
+            b1 |= wd == 1 ? shifted : 0u;
+            b2 |= wd == 2 ? shifted : 0u;
+            b3 |= wd == 3 ? shifted : 0u;
+            if (!a.assign_only) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int g = c * 2 + h;
+                    if (g < G) {
+                        const unsigned nib = (byte >> (4 * h)) & 15u;
+                        const double* row = Tp + (size_t)g * KT * kGroupM + nib;
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) acc[k] = acc[k] + row[k * kGroupM];
+                        if (has_minus) acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nib];
+                    }
+                }
+            }
+        }
+
+        int zn = a.assign_only ? zo : zoc;
+        if (!a.assign_only) {
+            // scores; the observation's own cluster is scored without itself
+            const double cm_own = Cm[zoc];
+            double m = neg_inf();
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                double s = Cp[k] + acc[k];
+                if (has_minus && k == zo) s = cm_own + acc_own;
+                acc[k] = s;
+                m = s > m ? s : m;
+            }
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const double w = exp_(acc[k] - m);
+                acc[k] = w;
+                tot = tot + w;
+            }
+            const double u = z_uniform(p.seed, (uint64_t)ic, a.sweep);
+            const double t = u * tot;
+            double cdf = 0.0;
+            int cnt = 0, last = -1;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                cdf = cdf + acc[k];
+                cnt += t >= cdf ? 1 : 0;
+                last = acc[k] > 0.0 ? k : last;
+            }
+            zn = cnt < KT ? cnt : last;
+            if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
+            if (p.mode == MODE_DP && zn == K) {
+                const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
+                if (Kused - own_single < K - 1) {
+                    zn = new_label;
+                    if (own_single && (zn < 0 || zo < zn)) zn = zo;
+                } else {
+                    int best = -1, bs = 0;
+                    for (int k = 0; k < K; ++k) {
+                        const int sz = NkT[k] - (k == zo ? 1 : 0);
+                        if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
+                    }
+                    zn = best >= 0 ? best : zoc;
+                }
+            }
+            if (valid) a.z_out[i] = zn;
+        } else if (valid && a.z_out != a.z_in) {
+            a.z_out[i] = zo;
+        }
+
+        // statistics: one mover at a time, one feature per lane
+        const int zfrom = a.assign_only ? -1 : zo;
+        unsigned long long movers = __ballot(valid && zn >= 0 && zn != zfrom);
+        while (movers) {
+            const int src = __ffsll((long long)movers) - 1;
+            movers &= movers - 1;
+            const int mzn = __builtin_amdgcn_readlane(zn, src);
+            const int mzo = __builtin_amdgcn_readlane(zfrom, src);
+            const uint32_t w0 = __builtin_amdgcn_readlane(b0, src), w1 = __builtin_amdgcn_readlane(b1, src);
+            const uint32_t w2 = __builtin_amdgcn_readlane(b2, src), w3 = __builtin_amdgcn_readlane(b3, src);
+            const uint32_t lo_w = lane < 32 ? w0 : w1, hi_w = lane < 32 ? w2 : w3;
+            const int sh = lane & 31;
+            if (lane < P && ((lo_w >> sh) & 1u)) {
+                atomicAdd(&hist[mzn * P + lane], 1);
+                if (mzo >= 0) atomicAdd(&hist[mzo * P + lane], -1);
+            }
+            if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
+                atomicAdd(&hist[mzn * P + lane + 64], 1);
+                if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
+            }
+            if (lane == 0) {
+                atomicAdd(&hist[K * P + mzn], 1);
+                if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int i = tid; i < nhist; i += NT) {
+        const int32_t v = hist[i];
+        if (v != 0) {
+            if (i < K * P) atomicAdd(&a.dS[i], v);
+            else atomicAdd(&a.dNk[i - K * P], v);
+        }
+    }
+}
+
+// S x N column-major 1-based output from the [S][N] 0-based device trace (tiled transpose)
+__global__ __launch_bounds__(256) void k_trace_to_r(const int32_t* __restrict__ trace, int64_t N, int S,
+                                                    int32_t* __restrict__ out) {
+    __shared__ int32_t tile[32][33];
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const int s0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int s = s0 + r;
+        const int64_t i = i0 + tx;
+        tile[r][tx] = (s < S && i < N) ? trace[(size_t)s * N + i] : 0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = i0 + r;
+        const int s = s0 + tx;
+        if (s < S && i < N) {
+            const int32_t v = tile[tx][r];
+            out[(size_t)i * S + s] = v < 0 ? (int32_t)0x80000000 : v + 1;
+        }
+    }
+}
+
+// ---- self-check kernels ----------------------------------------------------------
+__global__ void k_test_math(int op, const double* in, const double* in2, double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    double y;
+    if (op == 0) y = log_(x);
+    else if (op == 1) y = exp_(x);
+    else if (op == 2) y = div_(x, in2[i]);
+    else y = sqrt_(x);
+    out[i] = y;
+}
+__global__ void k_test_variates(int kind, double pp, double qq, uint64_t seed, uint32_t sweep, double* out,
+                                int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double y;
+    if (kind == 0) {
+        Stream s = make_stream(seed, (uint32_t)i, sweep, kStreamThetaA);
+        y = rgamma_(pp, s);
+    } else if (kind == 1) {
+        Stream sa = make_stream(seed, (uint32_t)i, sweep, kStreamThetaA);
+        Stream sb = make_stream(seed, (uint32_t)i, sweep, kStreamThetaB);
+        y = rbeta_(pp, qq, sa, sb);
+    } else {
+        y = update_alpha_(pp, 1.0, 1.0, 1000.0, (int)qq, seed + (uint64_t)i, sweep);
+    }
+    out[i] = y;
+}
+
+}  // namespace bmm

@@ -1,0 +1,58 @@
+"""No-GPU checks of the boundary: the library loads, exports every symbol the header
+declares, and refuses to run without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bmm_mcmc_amd as bm
+from bmm_mcmc_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "bmm_mcmc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bmm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_loader_agree():
+    assert _declared() == sorted(_capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.lib()
+    for s in _declared():
+        assert getattr(L, s) is not None
+
+
+def test_spec_constants_match_oracle(oracle):
+    assert _capi.lib().bmm_spec_group_width() == oracle.lib().oracle_group_width() == 4
+
+
+def test_default_batch_policy():
+    assert bm.default_batch("stickbreaking", 1000) == 1000
+    assert bm.default_batch("collapsed", 100) == 12
+    assert bm.default_batch("collapsed", 10 ** 7) == 1 << 20
+    assert bm.default_batch("dp", 3) == 1
+
+
+def test_argument_validation_needs_no_gpu():
+    X = np.zeros((10, 3), dtype=np.int32)
+    with pytest.raises(NotImplementedError, match="relabel"):
+        bm.gibbs_collapsed(X, 10, 2, relabel=True)
+    with pytest.raises(ValueError, match="binary"):
+        bm.gibbs_collapsed(X + 2, 10, 2)
+    with pytest.raises(ValueError, match="burnin"):
+        bm.gibbs_dp(X, 10, burnin=10)
+
+
+@pytest.mark.skipif(_capi.device_count() > 0, reason="a GPU is present")
+def test_no_cpu_fallback_without_a_device():
+    X = np.zeros((10, 3), dtype=np.int32)
+    with pytest.raises(bm.BmmError, match="no HIP device"):
+        bm.gibbs_collapsed(X, 10, 2, seed=1)
+    with pytest.raises(bm.BmmError, match="no HIP device"):
+        bm.Chain("dp", 10, 3, 5)

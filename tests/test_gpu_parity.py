@@ -1,0 +1,171 @@
+"""HIP path (through the C ABI and the Python mirror of the R wrappers) against the
+oracle on the same inputs and seed: labels, theta, pi and alpha must be bit-identical
+(integer z bit-exact under matched RNG; the floating-point outputs are produced by the
+same binary64 operation sequence, so they are compared exactly too)."""
+import numpy as np
+import pytest
+
+import bmm_mcmc_amd as bm
+from util import load_dataset, proportions, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _z0(N, K, seed):
+    return np.random.default_rng(seed).integers(1, K + 1, N).astype(np.int32)
+
+
+def _same(got, want, keys):
+    for k in keys:
+        assert got[k].shape == want[k].shape, k
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+# ---------------------------------------------------------------- finite collapsed sampler
+@pytest.mark.parametrize("batch", [1, 7, 100])
+def test_collapsed_bundled_c1_small(oracle, batch):
+    X = load_dataset("K2_N100_P5")
+    z0 = _z0(100, 2, 3)
+    got = bm.gibbs_collapsed(X, 60, 2, seed=11, batch=batch, initial_K=z0)
+    want = oracle.collapsed(X, z0, 60, 2, 0.0, 0.5, 0.5, 1, 1, 6, seed=11, batch=batch)
+    assert got["z"].shape == (54, 100) and got["theta"].shape == (2, 5, 54) and got["alpha"].shape == (54, 1)
+    assert got["permutations"].shape == (54, 2) and (got["permutations"] == bm.NA_INTEGER).all()
+    _same(got, want, ["z", "theta", "alpha"])
+
+
+def test_collapsed_config_c1_full(oracle):
+    # BASELINE config 1: bundled K2_N100_P5, 1 chain, 1000 iterations, burn-in 100
+    X = load_dataset("K2_N100_P5")
+    z0 = _z0(100, 2, 17)
+    got = bm.gibbs_collapsed(X, 1000, 2, seed=2019, batch=25, initial_K=z0)
+    want = oracle.collapsed(X, z0, 1000, 2, 0.0, 0.5, 0.5, 1, 1, 100, seed=2019, batch=25)
+    _same(got, want, ["z", "theta", "alpha"])
+    np.testing.assert_allclose(proportions(got["z"], 2), [0.7, 0.3], atol=0.05)
+
+
+@pytest.mark.parametrize("N,P,K,batch", [(4000, 20, 3, 512), (3001, 33, 7, 1000), (2500, 100, 20, 2500),
+                                         (1500, 128, 24, 300), (777, 1, 2, 50), (5000, 50, 20, 4096)])
+def test_collapsed_synthetic_shapes(oracle, N, P, K, batch):
+    X, _, _, _ = synth(N, P, min(K, 5), 18)
+    z0 = _z0(N, K, 5)
+    got = bm.gibbs_collapsed(X, 8, K, burnin=0, seed=99, batch=batch, initial_K=z0)
+    want = oracle.collapsed(X, z0, 8, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=99, batch=batch)
+    _same(got, want, ["z", "theta", "alpha"])
+    assert np.array_equal(got["z"][0], z0)  # burnin = 0: row 0 is the initial allocation
+
+
+def test_collapsed_fixed_alpha_asymmetric_prior(oracle):
+    X, _, _, _ = synth(3000, 17, 4, 21)
+    z0 = _z0(3000, 4, 1)
+    got = bm.gibbs_collapsed(X, 10, 4, alpha=2.5, beta=0.3, gamma=1.7, burnin=2, seed=5, batch=256, initial_K=z0)
+    want = oracle.collapsed(X, z0, 10, 4, 2.5, 0.3, 1.7, 1, 1, 2, seed=5, batch=256)
+    _same(got, want, ["z", "theta", "alpha"])
+    assert (got["alpha"] == 2.5).all()
+
+
+def test_collapsed_empty_cluster_stays_empty(oracle):
+    # collapsed_gibbs.cpp:104,131-133: an emptied cluster has probability 0 for ever; theta NaN (:214)
+    X = load_dataset("K3_N1000_P5")
+    z0 = np.ones(1000, dtype=np.int32)
+    z0[::2] = 2  # cluster 3 of 4 never used, cluster 4 holds one observation
+    z0[7] = 4
+    got = bm.gibbs_collapsed(X, 12, 4, burnin=1, seed=3, batch=64, initial_K=z0)
+    want = oracle.collapsed(X, z0, 12, 4, 0.0, 0.5, 0.5, 1, 1, 1, seed=3, batch=64)
+    _same(got, want, ["z", "theta", "alpha"])
+    assert not (got["z"] == 3).any()
+    assert np.isnan(got["theta"][2]).all()
+
+
+def test_collapsed_same_seed_same_chain_other_seed_other_chain():
+    X, _, _, _ = synth(6000, 12, 3, 18)
+    z0 = _z0(6000, 3, 2)
+    a = bm.gibbs_collapsed(X, 6, 3, seed=1, batch=1024, initial_K=z0)
+    b = bm.gibbs_collapsed(X, 6, 3, seed=1, batch=1024, initial_K=z0)
+    c = bm.gibbs_collapsed(X, 6, 3, seed=2, batch=1024, initial_K=z0)
+    assert np.array_equal(a["z"], b["z"]) and not np.array_equal(a["z"], c["z"])
+
+
+# ---------------------------------------------------------------- DP sampler
+@pytest.mark.parametrize("batch", [1, 13, 100])
+def test_dp_bundled(oracle, batch):
+    X = load_dataset("K2_N100_P5")
+    got = bm.gibbs_dp(X, 40, seed=77, batch=batch)
+    want = oracle.dp(X, 40, 0.0, 0.5, 0.5, 1, 1, 4, 30, seed=77, batch=batch)
+    assert got["theta"].shape == (30, 5, 36)
+    _same(got, want, ["z", "theta", "alpha"])
+
+
+@pytest.mark.parametrize("N,P,maxK,batch,alpha", [(3000, 20, 30, 256, 0.0), (2000, 50, 30, 2000, 0.0),
+                                                  (1000, 5, 3, 50, 5.0), (2500, 64, 12, 500, 1.0)])
+def test_dp_synthetic_and_truncation(oracle, N, P, maxK, batch, alpha):
+    X, _, _, _ = synth(N, P, 5, 19)
+    got = bm.gibbs_dp(X, 9, alpha=alpha, burnin=0, maxK=maxK, seed=4, batch=batch)
+    want = oracle.dp(X, 9, alpha, 0.5, 0.5, 1, 1, 0, maxK, seed=4, batch=batch)
+    _same(got, want, ["z", "theta", "alpha"])
+    assert (got["z"][0] == bm.NA_INTEGER).all()      # row 0 is never written by the reference
+    assert got["z"][1:].min() >= 1 and got["z"][1:].max() <= maxK
+
+
+def test_dp_rejects_asymmetric_prior():
+    X = load_dataset("K2_N100_P5")
+    with pytest.raises(bm.BmmError, match="non-symmetric"):
+        bm.gibbs_dp(X, 5, beta=0.5, gamma=0.7, seed=1)
+
+
+# ---------------------------------------------------------------- stick-breaking sampler
+def _sb_init(maxK, P, seed):
+    rng = np.random.default_rng(seed)
+    pi0 = np.exp(rng.random(maxK)); pi0 /= pi0.sum()
+    return pi0, rng.random((maxK, P))
+
+
+@pytest.mark.parametrize("name,maxK", [("K2_N100_P5", 6), ("K3_N1000_P5", 10)])
+def test_sb_bundled(oracle, name, maxK):
+    X = load_dataset(name)
+    pi0, th0 = _sb_init(maxK, 5, 3)
+    got = bm.gibbs_stickbreaking(X, 50, maxK, seed=31, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 50, maxK, 0.0, 0.5, 0.5, 1, 1, 5, seed=31)
+    assert got["pi"].shape == (45, maxK)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+
+
+@pytest.mark.parametrize("N,P,maxK", [(4000, 50, 50), (3000, 20, 10), (1234, 97, 33), (2000, 128, 64)])
+def test_sb_synthetic_shapes(oracle, N, P, maxK):
+    X, _, _, _ = synth(N, P, 6, 20)
+    pi0, th0 = _sb_init(maxK, P, 8)
+    got = bm.gibbs_stickbreaking(X, 7, maxK, burnin=0, seed=12, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 7, maxK, 0.0, 0.5, 0.5, 1, 1, 0, seed=12)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+    assert np.array_equal(got["pi"][0], pi0) and np.array_equal(got["theta"][:, :, 0], th0)
+
+
+# ---------------------------------------------------------------- resident chains and limits
+def test_resident_chain_matches_run_and_counts_are_consistent(oracle):
+    X, _, _, _ = synth(20000, 24, 4, 18)
+    z0 = _z0(20000, 4, 9)
+    with bm.Chain("collapsed", 20000, 24, 4, batch=4096, seed=5) as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(3)
+        ch.sweeps(2)
+        z = ch.labels()
+        Nk, S = ch.counts()
+        al = ch.alpha()
+    want = oracle.collapsed(X, z0, 6, 4, 0.0, 0.5, 0.5, 1, 1, 5, seed=5, batch=4096)
+    assert np.array_equal(z, want["z"][0])
+    assert al == want["alpha"][0, 0]
+    # size-independent property: the integer statistics equal a recount from the labels
+    assert np.array_equal(Nk, np.bincount(z - 1, minlength=4))
+    for k in range(4):
+        assert np.array_equal(S[k], X[z == k + 1].sum(axis=0))
+
+
+def test_unsupported_shapes_fail_loudly():
+    X = np.zeros((50, 200), dtype=np.int32)
+    with pytest.raises(bm.BmmError, match="exceeds"):
+        bm.gibbs_collapsed(X, 5, 2, seed=1)
+    X = np.zeros((50, 10), dtype=np.int32)
+    with pytest.raises(bm.BmmError, match="categories"):
+        bm.gibbs_collapsed(X, 5, 100, seed=1)
+    with pytest.raises(bm.BmmError, match="initialK"):
+        bm.gibbs_collapsed(X, 5, 2, seed=1, initial_K=np.full(50, 3))
