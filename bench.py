@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Gibbs sweeps/s of the cluster-allocation path on N MI355X GPUs (one chain per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one Gibbs sweep: every z_n resampled once, sufficient statistics and
+parameters refreshed.  Default workload "c5" is BASELINE.json's HBM-roofline
+configuration, one chain per GPU: gibbs_collapsed, K=20, N=1e7, P=100, synthetic.
+The data matrix is generated in HBM on rank 0 and broadcast over RCCL (the only
+collective on this path); chains are independent, so scaling is weak.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the z-resample kernel, timed with HIP
+events on the chain's own stream inside the timed region; algorithmic bytes are
+N*(4P+8) per sweep (int32 X row + z read + z write).
+`cpu_baseline` is the oracle's sufficient-statistics chain (same batch semantics) on the
+host cores of this box, on a bounded row sample, scaled to sweeps/s at the workload's N.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5", "ns"])
+    ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
+    ap.add_argument("--n", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import bmm_mcmc_amd as bm
+    from bmm_mcmc_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
+    if args.n:
+        N = args.n
+
+    # data: generated in HBM on rank 0, broadcast once over RCCL/xGMI
+    if rank == 0:
+        X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
+    else:
+        X = torch.empty((P, N), dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.broadcast(X, src=0)
+    torch.cuda.synchronize()
+
+    batch = args.batch if args.batch > 0 else bm.default_batch(sampler, N)
+    seed = 1000 + rank  # chain seeds 1000 + c
+    ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, batch=batch, seed=seed,
+                  device=local)
+    ch.set_data_device(X.data_ptr(), keepalive=X)
+    rng = np.random.default_rng(seed)
+    if sampler == "collapsed":
+        ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+    elif sampler == "stickbreaking":
+        pi0 = np.exp(rng.random(K))
+        ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ch.sweeps(args.warmup)
+    ch.sync()
+    ch.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    ch.sweeps(args.steps)
+    ch.sync()
+    barrier()
+    t1 = time.perf_counter()
+    kern_ms, kern_n = ch.profile_read()
+    ch.profile(False)
+    shape = ch.kernel_shape()
+
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    km = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    kern_ms = float(km.item())
+
+    result = None
+    if rank == 0:
+        bytes_per_sweep = N * (4 * P + 8)
+        achieved = (bytes_per_sweep * args.steps) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "gibbs_sweeps_per_s",
+            "value": world * args.steps / dt,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
+                       "sampler": sampler, "K": K, "N": N, "P": P, "batch": batch, "chains": world,
+                       "x_layout": "int32 column-major (as R hands it over)",
+                       "allocations_per_s": world * args.steps * N / dt},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_resample", "kernel_ms_per_sweep": kern_ms / args.steps,
+                         "launches_per_sweep": kern_n / args.steps,
+                         "algorithmic_bytes_per_sweep": bytes_per_sweep,
+                         "lds_bytes": shape["lds_bytes"], "threads": shape["threads"]},
+        }
+        if not args.no_cpu and world == 1:
+            from oracle import oracle
+            rows = min(args.cpu_rows, N)
+            Xh = np.asfortranarray(X[:, :rows].t().cpu().numpy())  # first `rows` shuffled rows
+            threads = min(os.cpu_count() or 1, 16)
+            cb = max(1, min(batch, rows))
+            probe = oracle.time_sweeps(sampler, Xh, K, 1, cb, 1000, threads)  # size the leg to ~cpu-seconds
+            cpu_sweeps = int(max(2, min(200, round(args.cpu_seconds / max(probe, 1e-3)))))
+            secs = oracle.time_sweeps(sampler, Xh, K, cpu_sweeps, cb, 1000, threads)
+            alloc_s = threads * rows * cpu_sweeps / secs
+            result["cpu_baseline"] = {
+                "value": alloc_s / N, "unit": "sweeps/s", "cores": threads, "kind": "port",
+                "sample": "%d independent chains (one per thread) x %d sweeps over the first %d rows; "
+                          "allocations/s / N" % (threads, cpu_sweeps, rows),
+                "allocations_per_s": alloc_s, "seconds": secs}
+            result["config"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    ch.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

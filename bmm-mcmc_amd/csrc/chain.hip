@@ -78,7 +78,7 @@ struct bmm_chain {
     hipStream_t stream = nullptr;
     int64_t batch = 1;
     double alpha0 = 1.0;
-    int NT = 0, grid_max = 0;
+    int NT = 0, grid_max = 0, minus_in_lds = 1;
     size_t lds_bytes = 0;
     resample_fn fn = nullptr;
 
@@ -153,7 +153,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
                     uint32_t sweep, int assign_only) {
     ResampleArgs a{};
     a.X = c->dX; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
-    a.lo = lo; a.hi = hi; a.sweep = sweep; a.assign_only = assign_only;
+    a.lo = lo; a.hi = hi; a.sweep = sweep; a.assign_only = assign_only; a.minus_in_lds = c->minus_in_lds;
     const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
     const int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -306,11 +306,15 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     }
     c->NT = threads_for(p.KT);
     c->fn = resample_kernel(p.KT);
-    c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + ((size_t)K * P + K) * sizeof(int32_t);
+    const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
+    c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
-    const size_t lds_cap = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 65536;
-    const size_t lds_max = lds_cap > 163840 ? lds_cap : 163840;  // gfx950: 160 KiB per workgroup
+    const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
+    if (c->lds_bytes > lds_max && p.mode != MODE_SB) {  // second tier: own-cluster tables stay in L2
+        c->minus_in_lds = 0;
+        c->lds_bytes = (size_t)layout_of(c).head() * sizeof(double) + hist_bytes;
+    }
     if (c->lds_bytes > lds_max) {
         const size_t need = c->lds_bytes;
         delete c;

@@ -31,20 +31,23 @@ constexpr int kMaxCats = 64;    // clusters (+ the DP's new-cluster option)
 
 enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2 };
 
-// Layout of the table image (identical in global memory and in LDS), in doubles:
+// Layout of the table image in global memory, in doubles:
 //   Tp  [G][KT][16]   group tables against the full statistics
-//   Tm  [G][KT][16]   ... with the scored observation's own contribution removed (not SB)
 //   Cp  [KT]          prior / weight term per category
-//   Cm  [KT]
-//   Nk  [KT] int32 (packed two per double slot)
+//   Cm  [KT]          ... with the scored observation removed from its own cluster
+//   Nk  [KT] int32    (two per double slot, padded to an even number of doubles)
+//   Tm  [G][KT][16]   group tables with the observation's own contribution removed (not SB)
+// A workgroup copies the head (Tp..Nk) into LDS, and Tm too when both fit in 160 KiB;
+// otherwise Tm is gathered from global memory (L2-resident, 1/K of the lookups).
 struct TableLayout {
     int G, KT, has_minus;
     __host__ __device__ int tp() const { return 0; }
-    __host__ __device__ int tm() const { return G * KT * kGroupM; }
-    __host__ __device__ int cp() const { return (has_minus ? 2 : 1) * G * KT * kGroupM; }
+    __host__ __device__ int cp() const { return G * KT * kGroupM; }
     __host__ __device__ int cm() const { return cp() + KT; }
-    __host__ __device__ int nk() const { return cm() + KT; }           // KT ints = KT/2 doubles
-    __host__ __device__ int doubles() const { return nk() + (KT + 1) / 2 + ((KT + 1) / 2 & 1); }  // even
+    __host__ __device__ int nk() const { return cm() + KT; }
+    __host__ __device__ int tm() const { return nk() + (KT + 1) / 2 + (((KT + 1) / 2) & 1); }
+    __host__ __device__ int head() const { return tm(); }
+    __host__ __device__ int doubles() const { return tm() + (has_minus ? G * KT * kGroupM : 0); }
 };
 
 struct ChainParams {
@@ -279,6 +282,7 @@ struct ResampleArgs {
     int64_t lo, hi;        // batch [lo, hi)
     uint32_t sweep;
     int assign_only;       // 1: z_out = z_in, count everything as arriving (initial statistics)
+    int minus_in_lds;      // 1: the Tm tables were sized into LDS too
 };
 
 template <int KT, int NT>
@@ -287,12 +291,14 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const bool has_minus = p.mode != MODE_SB;
     const TableLayout L{p.G, KT, has_minus ? 1 : 0};
     double* const lds = reinterpret_cast<double*>(smem);
+    const int lds_doubles = (has_minus && a.minus_in_lds) ? L.doubles() : L.head();
     const double* const Tp = lds + L.tp();
-    const double* const Tm = lds + L.tm();
+    const double* const TmL = lds + L.tm();
+    const double* const TmG = a.tab + L.tm();
     const double* const Cp = lds + L.cp();
     const double* const Cm = lds + L.cm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(lds + L.nk());
-    int32_t* const hist = reinterpret_cast<int32_t*>(lds + L.doubles());  // [K*P] then [K]
+    int32_t* const hist = reinterpret_cast<int32_t*>(lds + lds_doubles);  // [K*P] then [K]
     const int P = p.P, G = p.G, K = p.K;
     const int nhist = K * P + K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     if (!a.assign_only) {
         const double2* src = reinterpret_cast<const double2*>(a.tab);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < L.doubles() / 2; i += NT) dst[i] = src[i];
+        for (int i = tid; i < lds_doubles / 2; i += NT) dst[i] = src[i];
     }
     for (int i = tid; i < nhist; i += NT) hist[i] = 0;
     __syncthreads();
@@ -357,7 +363,10 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                         const double* row = Tp + (size_t)g * KT * kGroupM + nib;
 #pragma unroll
                         for (int k = 0; k < KT; ++k) acc[k] = acc[k] + row[k * kGroupM];
-                        if (has_minus) acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nib];
+                        if (has_minus) {
+                            const size_t off = ((size_t)g * KT + zoc) * kGroupM + nib;
+                            acc_own = acc_own + (a.minus_in_lds ? TmL[off] : TmG[off]);
+                        }
                     }
                 }
             }

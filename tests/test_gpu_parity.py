@@ -129,7 +129,7 @@ def test_sb_bundled(oracle, name, maxK):
     _same(got, want, ["z", "theta", "alpha", "pi"])
 
 
-@pytest.mark.parametrize("N,P,maxK", [(4000, 50, 50), (3000, 20, 10), (1234, 97, 33), (2000, 128, 64)])
+@pytest.mark.parametrize("N,P,maxK", [(4000, 50, 50), (3000, 20, 10), (1234, 97, 33), (2000, 128, 36), (1500, 60, 64)])
 def test_sb_synthetic_shapes(oracle, N, P, maxK):
     X, _, _, _ = synth(N, P, 6, 20)
     pi0, th0 = _sb_init(maxK, P, 8)
@@ -164,6 +164,9 @@ def test_unsupported_shapes_fail_loudly():
     X = np.zeros((50, 200), dtype=np.int32)
     with pytest.raises(bm.BmmError, match="exceeds"):
         bm.gibbs_collapsed(X, 5, 2, seed=1)
+    X = np.zeros((50, 128), dtype=np.int32)
+    with pytest.raises(bm.BmmError, match="LDS"):
+        bm.gibbs_collapsed(X, 5, 60, seed=1)
     X = np.zeros((50, 10), dtype=np.int32)
     with pytest.raises(bm.BmmError, match="categories"):
         bm.gibbs_collapsed(X, 5, 100, seed=1)
