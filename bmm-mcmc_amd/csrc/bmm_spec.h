@@ -140,11 +140,13 @@ BMM_HD double log_(double x) {
 // exp(x): k = round(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r, scale by 2^k.
 // Results below 2^-1021 are flushed to 0 (x < -708); the sampler never needs them.
 BMM_HD double exp_(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return pos_inf();
-    if (x < -708.0) return 0.0;
-    const double kd = floor_(fma_(x, 1.44269504088896338700e+00, 0.5));
-    double r = fma_(-kd, 6.93147180369123816490e-01, x);
+    // written select-style (no early returns) so that the device code is branch-free
+    const bool is_nan = x != x;
+    const bool over = x > 709.782712893384;
+    const bool under = x < -708.0;
+    const double xs = (is_nan || over || under) ? 0.0 : x;
+    const double kd = floor_(fma_(xs, 1.44269504088896338700e+00, 0.5));
+    double r = fma_(-kd, 6.93147180369123816490e-01, xs);
     r = fma_(-kd, 1.90821492927058770002e-10, r);
     double p = 1.6059043836821614599e-10;            // 1/13!
     p = fma_(p, r, 2.0876756987868098979e-09);       // 1/12!
@@ -161,8 +163,11 @@ BMM_HD double exp_(double x) {
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
     int k = (int)kd;
-    if (k > 1023) { p = p * 2.0; k -= 1; }
-    return p * dfrom((uint64_t)(k + 1023) << 52);
+    const bool top = k > 1023;
+    p = top ? p * 2.0 : p;
+    k = top ? k - 1 : k;
+    const double y = p * dfrom((uint64_t)(k + 1023) << 52);
+    return is_nan ? x : (over ? pos_inf() : (under ? 0.0 : y));
 }
 
 // ---------------------------------------------------------------- variates

@@ -41,15 +41,17 @@ int set_err(int code, const char* fmt, ...) {
 
 // accumulator counts the resample kernel is instantiated for
 const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
-constexpr int kThreadsSmall = 1024;  // KT <= 24: <= 128 VGPRs per lane
-constexpr int kThreadsLarge = 512;
+// workgroup size by accumulator count: the VGPR budget per lane is 512 / (waves per SIMD)
+constexpr int kThreadsSmall = 1024;  // KT <= 16: 128 VGPRs
+constexpr int kThreadsMid = 768;     // KT <= 24: 168 VGPRs
+constexpr int kThreadsLarge = 512;   // 256 VGPRs
 
 int pick_kt(int cats) {
     for (int kt : kKT)
         if (kt >= cats) return kt;
     return -1;
 }
-int threads_for(int kt) { return kt <= 24 ? kThreadsSmall : kThreadsLarge; }
+int threads_for(int kt) { return kt <= 16 ? kThreadsSmall : (kt <= 24 ? kThreadsMid : kThreadsLarge); }
 
 typedef void (*resample_fn)(ChainParams, ResampleArgs);
 resample_fn resample_kernel(int kt) {
@@ -58,8 +60,8 @@ resample_fn resample_kernel(int kt) {
         case 8: return k_resample<8, kThreadsSmall>;
         case 12: return k_resample<12, kThreadsSmall>;
         case 16: return k_resample<16, kThreadsSmall>;
-        case 20: return k_resample<20, kThreadsSmall>;
-        case 24: return k_resample<24, kThreadsSmall>;
+        case 20: return k_resample<20, kThreadsMid>;
+        case 24: return k_resample<24, kThreadsMid>;
         case 28: return k_resample<28, kThreadsLarge>;
         case 32: return k_resample<32, kThreadsLarge>;
         case 40: return k_resample<40, kThreadsLarge>;

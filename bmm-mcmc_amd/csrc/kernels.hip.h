@@ -26,6 +26,8 @@
 
 namespace bmm {
 
+typedef __attribute__((address_space(3))) double lds_f64;  // LDS-qualified, keeps ds_read under volatile
+
 constexpr int kMaxP = 128;      // 4 bit-words per observation
 constexpr int kMaxCats = 64;    // clusters (+ the DP's new-cluster option)
 
@@ -285,6 +287,69 @@ struct ResampleArgs {
     int minus_in_lds;      // 1: the Tm tables were sized into LDS too
 };
 
+// Where a lane sits in a tile of NT consecutive observations.  Lanes past the end of the
+// batch re-read its last observation (and never write back).
+struct TilePos {
+    const char* base;   // wave-uniform byte address of X[wave_base + 0*N]
+    uint32_t voff;      // this lane's byte offset from it (>= 0)
+    int64_t i, ic;      // own observation, clamped observation
+    bool valid;
+};
+__device__ __forceinline__ TilePos tile_pos(const ResampleArgs& a, int64_t tile, int NT, int tid, int lane) {
+    TilePos t;
+    const int64_t tile_base = a.lo + tile * NT;
+    t.i = tile_base + tid;
+    t.valid = t.i < a.hi;
+    int64_t wave_base = tile_base + (int64_t)__builtin_amdgcn_readfirstlane(tid & ~63);  // SGPR
+    wave_base = wave_base < a.hi ? wave_base : a.hi - 1;
+    const int64_t room = a.hi - 1 - wave_base;
+    const int lane_off = lane < room ? lane : (int)room;
+    t.ic = wave_base + lane_off;
+    t.voff = (uint32_t)lane_off * 4u;
+    t.base = reinterpret_cast<const char*>(a.X + wave_base);
+    return t;
+}
+// Issue the loads of bit-word wd (features 32*wd ...): 32 coalesced dword loads per lane,
+// wave-uniform base + zero-extended 32-bit lane offset (global_load saddr form).
+// buffer form: the descriptor (SGPRs) carries the wave-uniform column base and is advanced
+// by the column stride between loads; the lane offset is one shared VGPR.  No per-load
+// address registers: the kStage loads of one stage are in flight from kStage + 1 VGPRs.
+constexpr int kStage = 16;  // features per pipeline stage (= 4 lookup groups)
+
+__device__ __forceinline__ void issue_stage(const TilePos& t, int64_t N, int P, int h, uint32_t (&st)[kStage]) {
+    const int d0 = h * kStage;
+    const int64_t stride = N * 4;
+    // a partial last stage re-reads feature P-1 (same cache lines); pack_stage masks it off
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+        const int d = d0 + u < P ? d0 + u : P - 1;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(t.base + d * stride), 0, 0x7fffffff, 0x00020000);
+        st[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)t.voff, 0, 0);
+    }
+}
+__device__ __forceinline__ uint32_t pack_stage(int P, int h, const uint32_t (&st)[kStage]) {
+    const int nb = P - h * kStage < kStage ? P - h * kStage : kStage;
+    uint32_t v = 0;
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) v |= (st[u] & 1u) << u;
+    return v & ((1u << nb) - 1u);
+}
+// bits of stage h live in word h/2 at bit 16*(h%2)
+__device__ __forceinline__ void put_stage(uint32_t v, int h, uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    const uint32_t sh = v << ((h & 1) * kStage);
+    const int w = h >> 1;
+    b0 |= w == 0 ? sh : 0u;
+    b1 |= w == 1 ? sh : 0u;
+    b2 |= w == 2 ? sh : 0u;
+    b3 |= w == 3 ? sh : 0u;
+}
+
+// Software pipeline per wave: while tile t is scored from LDS (segment h = the 4 lookup
+// groups of feature stage h), the 16 loads of stage h of tile t+1 are in flight; they are
+// packed after the segment and the loads of stage h+1 issued.  HBM latency therefore hides behind
+// the wave's own LDS/VALU work instead of every wave of the CU loading, then computing,
+// in lockstep.
 template <int KT, int NT>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -322,130 +387,162 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 
     const int64_t span = a.hi - a.lo;
     const int64_t ntiles = (span + NT - 1) / NT;
-    const int nchunks = (P + 7) / 8;
+    const int nstages = (P + kStage - 1) / kStage;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t i = a.lo + tile * NT + tid;
-        const bool valid = i < a.hi;
-        const int64_t ic = valid ? i : a.hi - 1;
-        const int zo = a.z_in ? a.z_in[ic] : -1;
-        const int zoc = zo < 0 ? 0 : zo;
-        const int32_t* xcol = a.X + ic;
-
-        double acc[KT];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        uint32_t st[kStage];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) acc[k] = 0.0;
-        double acc_own = 0.0;
+        for (int u = 0; u < kStage; ++u) st[u] = 0;
+        TilePos pos = tile_pos(a, tile, NT, tid, lane);
+        // prologue: the first tile's features, nothing to overlap with yet
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll 1
+        for (int h = 0; h < nstages; ++h) {
+            issue_stage(pos, p.N, P, h, st);
+            put_stage(pack_stage(P, h, st), h, b0, b1, b2, b3);
+        }
+        int zo = a.z_in ? a.z_in[pos.ic] : -1;
+        asm volatile("" : "+v"(zo));  // land it before the pipeline starts (see below)
 
-        for (int c = 0; c < nchunks; ++c) {
-            // eight features: 8 coalesced dword loads in flight per lane
-            uint32_t byte = 0;
-            const int d0 = c * 8;
+        for (;;) {
+            const int64_t next = tile + gridDim.x;
+            const bool has_next = next < ntiles;  // uniform
+            const TilePos npos = tile_pos(a, has_next ? next : tile, NT, tid, lane);
+            uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+            int zo_next = -1;
+            if (has_next) issue_stage(npos, p.N, P, 0, st);
+            const int zoc = zo < 0 ? 0 : zo;
+
+            // ---- scoring: K * G conflict-free LDS lookups (volatile: one ds_read_b64 each;
+            // the compiler would otherwise pair them into ds_read2_b64 at half the bytes/clk).
+            // Clusters are read eight at a time so that at most 16 result registers are live.
+            double acc[KT];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int d = d0 + t < P ? d0 + t : P - 1;
-                const uint32_t v = (uint32_t)xcol[(int64_t)d * p.N];
-                byte |= (d0 + t < P ? (v & 1u) : 0u) << t;
-            }
-            const uint32_t shifted = byte << ((c & 3) * 8);
-            const int wd = c >> 2;
-            b0 |= wd == 0 ? shifted : 0u;
-            b1 |= wd == 1 ? shifted : 0u;
-            b2 |= wd == 2 ? shifted : 0u;
-            b3 |= wd == 3 ? shifted : 0u;
-            if (!a.assign_only) {
+            for (int k = 0; k < KT; ++k) acc[k] = 0.0;
+            double acc_own = 0.0;
+#pragma unroll 1
+            for (int h = 0; h < nstages; ++h) {
+                if (!a.assign_only) {
+                    const uint32_t word = (h >> 1) == 0 ? b0 : ((h >> 1) == 1 ? b1 : ((h >> 1) == 2 ? b2 : b3));
+                    const uint32_t half = word >> ((h & 1) * kStage);
+                    const int g_hi = G < h * 4 + 4 ? G : h * 4 + 4;
+#pragma unroll 1
+                    for (int g = h * 4; g < g_hi; ++g) {
+                        const unsigned nib = (half >> ((g & 3) * 4)) & 15u;
+                        const volatile lds_f64* row =
+                            (const volatile lds_f64*)Tp + ((size_t)g * KT * kGroupM + nib);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int g = c * 2 + h;
-                    if (g < G) {
-                        const unsigned nib = (byte >> (4 * h)) & 15u;
-                        const double* row = Tp + (size_t)g * KT * kGroupM + nib;
+                        for (int k0 = 0; k0 < KT; k0 += 8) {
 #pragma unroll
-                        for (int k = 0; k < KT; ++k) acc[k] = acc[k] + row[k * kGroupM];
+                            for (int k = k0; k < (k0 + 8 < KT ? k0 + 8 : KT); ++k)
+                                acc[k] = acc[k] + row[k * kGroupM];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if (has_minus) {
                             const size_t off = ((size_t)g * KT + zoc) * kGroupM + nib;
-                            acc_own = acc_own + (a.minus_in_lds ? TmL[off] : TmG[off]);
+                            double own;
+                            if (a.minus_in_lds) own = ((const lds_f64*)TmL)[off];
+                            else own = TmG[off];
+                            acc_own = acc_own + own;
                         }
                     }
                 }
-            }
-        }
-
-        int zn = a.assign_only ? zo : zoc;
-        if (!a.assign_only) {
-            // scores; the observation's own cluster is scored without itself
-            const double cm_own = Cm[zoc];
-            double m = neg_inf();
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                double s = Cp[k] + acc[k];
-                if (has_minus && k == zo) s = cm_own + acc_own;
-                acc[k] = s;
-                m = s > m ? s : m;
-            }
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const double w = exp_(acc[k] - m);
-                acc[k] = w;
-                tot = tot + w;
-            }
-            const double u = z_uniform(p.seed, (uint64_t)ic, a.sweep);
-            const double t = u * tot;
-            double cdf = 0.0;
-            int cnt = 0, last = -1;
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                cdf = cdf + acc[k];
-                cnt += t >= cdf ? 1 : 0;
-                last = acc[k] > 0.0 ? k : last;
-            }
-            zn = cnt < KT ? cnt : last;
-            if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
-            if (p.mode == MODE_DP && zn == K) {
-                const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
-                if (Kused - own_single < K - 1) {
-                    zn = new_label;
-                    if (own_single && (zn < 0 || zo < zn)) zn = zo;
-                } else {
-                    int best = -1, bs = 0;
-                    for (int k = 0; k < K; ++k) {
-                        const int sz = NkT[k] - (k == zo ? 1 : 0);
-                        if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
-                    }
-                    zn = best >= 0 ? best : zoc;
+                if (has_next) {  // stage h of the next tile has landed by now; fetch stage h+1
+                    put_stage(pack_stage(P, h, st), h, n0, n1, n2, n3);
+                    if (h + 1 < nstages) issue_stage(npos, p.N, P, h + 1, st);
                 }
             }
-            if (valid) a.z_out[i] = zn;
-        } else if (valid && a.z_out != a.z_in) {
-            a.z_out[i] = zo;
-        }
 
-        // statistics: one mover at a time, one feature per lane
-        const int zfrom = a.assign_only ? -1 : zo;
-        unsigned long long movers = __ballot(valid && zn >= 0 && zn != zfrom);
-        while (movers) {
-            const int src = __ffsll((long long)movers) - 1;
-            movers &= movers - 1;
-            const int mzn = __builtin_amdgcn_readlane(zn, src);
-            const int mzo = __builtin_amdgcn_readlane(zfrom, src);
-            const uint32_t w0 = __builtin_amdgcn_readlane(b0, src), w1 = __builtin_amdgcn_readlane(b1, src);
-            const uint32_t w2 = __builtin_amdgcn_readlane(b2, src), w3 = __builtin_amdgcn_readlane(b3, src);
-            const uint32_t lo_w = lane < 32 ? w0 : w1, hi_w = lane < 32 ? w2 : w3;
-            const int sh = lane & 31;
-            if (lane < P && ((lo_w >> sh) & 1u)) {
-                atomicAdd(&hist[mzn * P + lane], 1);
-                if (mzo >= 0) atomicAdd(&hist[mzo * P + lane], -1);
+            // every stage of the next tile is packed; its previous label is fetched now, with
+            // nothing else in flight, and lands during the draw below
+            if (has_next && a.z_in) zo_next = a.z_in[npos.ic];
+
+            int zn = a.assign_only ? zo : zoc;
+            if (!a.assign_only) {
+                // scores; the observation's own cluster is scored without itself
+                const double cm_own = Cm[zoc];
+                double m = neg_inf();
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    double sc = Cp[k] + acc[k];
+                    if (has_minus && k == zo) sc = cm_own + acc_own;
+                    acc[k] = sc;
+                    m = sc > m ? sc : m;
+                }
+                double tot = 0.0;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const double w = exp_(acc[k] - m);
+                    acc[k] = w;
+                    tot = tot + w;
+                }
+                const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
+                const double t = u * tot;
+                double cdf = 0.0;
+                int cnt = 0, last = -1;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    cdf = cdf + acc[k];
+                    cnt += t >= cdf ? 1 : 0;
+                    last = acc[k] > 0.0 ? k : last;
+                }
+                zn = cnt < KT ? cnt : last;
+                if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
+                if (p.mode == MODE_DP && zn == K) {
+                    const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
+                    if (Kused - own_single < K - 1) {
+                        zn = new_label;
+                        if (own_single && (zn < 0 || zo < zn)) zn = zo;
+                    } else {
+                        int best = -1, bs = 0;
+                        for (int k = 0; k < K; ++k) {
+                            const int sz = NkT[k] - (k == zo ? 1 : 0);
+                            if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
+                        }
+                        zn = best >= 0 ? best : zoc;
+                    }
+                }
+                if (pos.valid) a.z_out[pos.i] = zn;
+            } else if (pos.valid && a.z_out != a.z_in) {
+                a.z_out[pos.i] = zo;
             }
-            if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
-                atomicAdd(&hist[mzn * P + lane + 64], 1);
-                if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
+
+            // statistics: one mover at a time, one feature per lane
+            const int zfrom = a.assign_only ? -1 : zo;
+            unsigned long long movers = __ballot(pos.valid && zn >= 0 && zn != zfrom);
+            while (movers) {
+                const int src = __ffsll((long long)movers) - 1;
+                movers &= movers - 1;
+                const int mzn = __builtin_amdgcn_readlane(zn, src);
+                const int mzo = __builtin_amdgcn_readlane(zfrom, src);
+                const uint32_t w0 = __builtin_amdgcn_readlane(b0, src), w1 = __builtin_amdgcn_readlane(b1, src);
+                const uint32_t w2 = __builtin_amdgcn_readlane(b2, src), w3 = __builtin_amdgcn_readlane(b3, src);
+                const uint32_t lo_w = lane < 32 ? w0 : w1, hi_w = lane < 32 ? w2 : w3;
+                const int sh = lane & 31;
+                if (lane < P && ((lo_w >> sh) & 1u)) {
+                    atomicAdd(&hist[mzn * P + lane], 1);
+                    if (mzo >= 0) atomicAdd(&hist[mzo * P + lane], -1);
+                }
+                if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
+                    atomicAdd(&hist[mzn * P + lane + 64], 1);
+                    if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
+                }
+                if (lane == 0) {
+                    atomicAdd(&hist[K * P + mzn], 1);
+                    if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
+                }
             }
-            if (lane == 0) {
-                atomicAdd(&hist[K * P + mzn], 1);
-                if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
-            }
+
+            if (!has_next) break;
+            b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+            // retire the label prefetch here, while it is the only load outstanding: a wait
+            // in the next iteration would sit behind that iteration's stage loads (vmcnt is
+            // in order) and drain them
+            asm volatile("" : "+v"(zo_next));
+            zo = zo_next;
+            pos = npos;
+            tile = next;
         }
     }
 
