@@ -42,8 +42,8 @@ int set_err(int code, const char* fmt, ...) {
 // accumulator counts the resample kernel is instantiated for
 const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
 // workgroup size by accumulator count: the VGPR budget per lane is 512 / (waves per SIMD)
-constexpr int kThreadsSmall = 1024;  // KT <= 16: 128 VGPRs
-constexpr int kThreadsMid = 768;     // KT <= 24: 168 VGPRs
+constexpr int kThreadsSmall = 1024;  // KT <= 12: 128 VGPRs
+constexpr int kThreadsMid = 768;     // KT 16, 20: 168 VGPRs
 constexpr int kThreadsLarge = 512;   // 256 VGPRs
 
 int pick_kt(int cats) {
@@ -51,25 +51,30 @@ int pick_kt(int cats) {
         if (kt >= cats) return kt;
     return -1;
 }
-int threads_for(int kt) { return kt <= 16 ? kThreadsSmall : (kt <= 24 ? kThreadsMid : kThreadsLarge); }
+int threads_for(int kt) { return kt <= 12 ? kThreadsSmall : (kt <= 20 ? kThreadsMid : kThreadsLarge); }
 
 typedef void (*resample_fn)(ChainParams, ResampleArgs);
-resample_fn resample_kernel(int kt) {
+template <int MINUS>
+resample_fn resample_kernel_m(int kt) {
     switch (kt) {
-        case 4: return k_resample<4, kThreadsSmall>;
-        case 8: return k_resample<8, kThreadsSmall>;
-        case 12: return k_resample<12, kThreadsSmall>;
-        case 16: return k_resample<16, kThreadsSmall>;
-        case 20: return k_resample<20, kThreadsMid>;
-        case 24: return k_resample<24, kThreadsMid>;
-        case 28: return k_resample<28, kThreadsLarge>;
-        case 32: return k_resample<32, kThreadsLarge>;
-        case 40: return k_resample<40, kThreadsLarge>;
-        case 48: return k_resample<48, kThreadsLarge>;
-        case 56: return k_resample<56, kThreadsLarge>;
-        case 64: return k_resample<64, kThreadsLarge>;
+        case 4: return k_resample<4, kThreadsSmall, MINUS>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS>;
+        case 16: return k_resample<16, kThreadsMid, MINUS>;
+        case 20: return k_resample<20, kThreadsMid, MINUS>;
+        case 24: return k_resample<24, kThreadsLarge, MINUS>;
+        case 28: return k_resample<28, kThreadsLarge, MINUS>;
+        case 32: return k_resample<32, kThreadsLarge, MINUS>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS>;
     }
     return nullptr;
+}
+// minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
+resample_fn resample_kernel(int kt, int minus) {
+    return minus == 0 ? resample_kernel_m<0>(kt) : (minus == 1 ? resample_kernel_m<1>(kt) : resample_kernel_m<2>(kt));
 }
 
 }  // namespace
@@ -97,6 +102,7 @@ struct bmm_chain {
     int32_t* dTrace = nullptr;  // [S][N], 0-based
     double *dThetaTrace = nullptr, *dAlphaTrace = nullptr, *dPiTrace = nullptr;
 
+    unsigned long long* dDiag = nullptr;
     bool prof = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -147,19 +153,23 @@ int chain_alloc(bmm_chain* c) {
     HIP_TRY(hipMemsetAsync(c->dTab, 0, (size_t)layout_of(c).doubles() * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz, c->stream));  // -1 = unassigned
     HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
+#ifdef BMM_DIAG
+    HIP_TRY(hipMalloc(&c->dDiag, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->dDiag, 0, 8 * sizeof(unsigned long long), c->stream));
+#endif
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
 }
 
 int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t lo, int64_t hi,
-                    uint32_t sweep, int assign_only) {
+                    uint32_t sweep) {
     ResampleArgs a{};
     a.X = c->dX; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
-    a.lo = lo; a.hi = hi; a.sweep = sweep; a.assign_only = assign_only; a.minus_in_lds = c->minus_in_lds;
+    a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
     const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
     const int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->prof && !assign_only) {
+    if (c->prof) {
         if (c->ev_used + 2 > c->ev.size()) {
             hipEvent_t a0, a1;
             HIP_TRY(hipEventCreate(&a0));
@@ -193,7 +203,7 @@ int enqueue_sweep(bmm_chain* c, int j) {
     double* th_tr = rec ? c->dThetaTrace + (size_t)s * p.K * p.P : nullptr;
     double* al_tr = rec ? c->dAlphaTrace + s : nullptr;
     if (p.mode == MODE_SB) {
-        int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j, 0);
+        int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
@@ -214,7 +224,7 @@ int enqueue_sweep(bmm_chain* c, int j) {
         const int64_t hi = lo + len > p.N ? p.N : lo + len;
         int rc = launch_count_tables(c);
         if (rc) return rc;
-        rc = launch_resample(c, zin, zout, lo, hi, (uint32_t)j, 0);
+        rc = launch_resample(c, zin, zout, lo, hi, (uint32_t)j);
         if (rc) return rc;
         lo = hi;
     }
@@ -238,8 +248,11 @@ int chain_start(bmm_chain* c) {
         if (row0 != c->dZ[0])
             HIP_TRY(hipMemcpyAsync(row0, c->dZ[0], (size_t)p.N * sizeof(int32_t), hipMemcpyDeviceToDevice,
                                    c->stream));
-        int rc = launch_resample(c, row0, row0, 0, p.N, 0, 1);
-        if (rc) return rc;
+        const size_t hb = ((size_t)p.K * p.P + p.K) * sizeof(int32_t);
+        const int64_t nt = (p.N + 255) / 256;
+        hipLaunchKernelGGL(k_count_labels, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), hb, c->stream, p,
+                           c->dX, row0, c->dDNk, c->dDS);
+        HIP_TRY(hipGetLastError());
     } else if (p.mode == MODE_SB) {
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
                            c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab);
@@ -307,7 +320,6 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build tabulates on chip", p.Kc, kMaxCats);
     }
     c->NT = threads_for(p.KT);
-    c->fn = resample_kernel(p.KT);
     const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
     c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
     hipDeviceProp_t prop;
@@ -322,6 +334,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         delete c;
         return set_err(BMM_E_UNSUPPORTED, "K = %d, P = %d need %zu bytes of LDS tables; the CU has %zu", K, P, need, lds_max);
     }
+    c->fn = resample_kernel(p.KT, p.mode == MODE_SB ? 0 : (c->minus_in_lds ? 1 : 2));
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -341,6 +354,18 @@ void bmm_chain_destroy(bmm_chain* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef BMM_DIAG
+    if (c->dDiag) {
+        unsigned long long d[8];
+        if (hipMemcpy(d, c->dDiag, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && d[5]) {
+            const double tot = (double)(d[0] + d[1] + d[2] + d[3] + d[4]);
+            fprintf(stderr, "[bmm diag] waves=%llu cycles/wave: score %.0f (%.1f%%) pack %.0f (%.1f%%) draw %.0f (%.1f%%) movers %.0f (%.1f%%) prologue %.0f (%.1f%%)\n",
+                    d[5], d[0] / (double)d[5], 100 * d[0] / tot, d[1] / (double)d[5], 100 * d[1] / tot, d[2] / (double)d[5],
+                    100 * d[2] / tot, d[3] / (double)d[5], 100 * d[3] / tot, d[4] / (double)d[5], 100 * d[4] / tot);
+        }
+        (void)hipFree(c->dDiag);
+    }
+#endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
                     c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace};

@@ -283,8 +283,8 @@ struct ResampleArgs {
     int32_t* dS;
     int64_t lo, hi;        // batch [lo, hi)
     uint32_t sweep;
-    int assign_only;       // 1: z_out = z_in, count everything as arriving (initial statistics)
     int minus_in_lds;      // 1: the Tm tables were sized into LDS too
+    unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
 };
 
 // Where a lane sits in a tile of NT consecutive observations.  Lanes past the end of the
@@ -319,13 +319,14 @@ constexpr int kStage = 16;  // features per pipeline stage (= 4 lookup groups)
 __device__ __forceinline__ void issue_stage(const TilePos& t, int64_t N, int P, int h, uint32_t (&st)[kStage]) {
     const int d0 = h * kStage;
     const int64_t stride = N * 4;
+    const char* col = t.base + (int64_t)d0 * stride;
     // a partial last stage re-reads feature P-1 (same cache lines); pack_stage masks it off
 #pragma unroll
     for (int u = 0; u < kStage; ++u) {
-        const int d = d0 + u < P ? d0 + u : P - 1;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(t.base + d * stride), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(col), 0, 0x7fffffff, 0x00020000);
         st[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)t.voff, 0, 0);
+        col += d0 + u + 1 < P ? stride : 0;
     }
 }
 __device__ __forceinline__ uint32_t pack_stage(int P, int h, const uint32_t (&st)[kStage]) {
@@ -344,216 +345,285 @@ __device__ __forceinline__ void put_stage(uint32_t v, int h, uint32_t& b0, uint3
     b2 |= w == 2 ? sh : 0u;
     b3 |= w == 3 ? sh : 0u;
 }
+__device__ __forceinline__ unsigned nibble_of(int g, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    const uint32_t word = g < 8 ? b0 : (g < 16 ? b1 : (g < 24 ? b2 : b3));
+    return (word >> ((g & 7) * 4)) & 15u;
+}
 
-// Software pipeline per wave: while tile t is scored from LDS (segment h = the 4 lookup
-// groups of feature stage h), the 16 loads of stage h of tile t+1 are in flight; they are
-// packed after the segment and the loads of stage h+1 issued.  HBM latency therefore hides behind
-// the wave's own LDS/VALU work instead of every wave of the CU loading, then computing,
-// in lockstep.
-template <int KT, int NT>
-__global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+// Sufficient-statistic deltas of one wave's movers into the workgroup's LDS histogram:
+// one mover at a time, one feature per lane (conflict-free, integer, order-independent).
+__device__ __forceinline__ void count_movers(bool moves, int zfrom, int zto, uint32_t b0, uint32_t b1,
+                                             uint32_t b2, uint32_t b3, int32_t* hist, int K, int P, int lane) {
+    unsigned long long movers = __ballot(moves);
+    while (movers) {
+        const int src = __ffsll((long long)movers) - 1;
+        movers &= movers - 1;
+        const int mzn = __builtin_amdgcn_readlane(zto, src);
+        const int mzo = __builtin_amdgcn_readlane(zfrom, src);
+        const uint32_t w0 = __builtin_amdgcn_readlane(b0, src), w1 = __builtin_amdgcn_readlane(b1, src);
+        const uint32_t w2 = __builtin_amdgcn_readlane(b2, src), w3 = __builtin_amdgcn_readlane(b3, src);
+        const uint32_t lo_w = lane < 32 ? w0 : w1, hi_w = lane < 32 ? w2 : w3;
+        const int sh = lane & 31;
+        if (lane < P && ((lo_w >> sh) & 1u)) {
+            atomicAdd(&hist[mzn * P + lane], 1);
+            if (mzo >= 0) atomicAdd(&hist[mzo * P + lane], -1);
+        }
+        if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
+            atomicAdd(&hist[mzn * P + lane + 64], 1);
+            if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
+        }
+        if (lane == 0) {
+            atomicAdd(&hist[K * P + mzn], 1);
+            if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
+        }
+    }
+}
+__device__ __forceinline__ void flush_hist(const int32_t* hist, int K, int P, int32_t* dS, int32_t* dNk,
+                                           int tid, int nt) {
+    for (int i = tid; i < K * P + K; i += nt) {
+        const int32_t v = hist[i];
+        if (v != 0) {
+            if (i < K * P) atomicAdd(&dS[i], v);
+            else atomicAdd(&dNk[i - K * P], v);
+        }
+    }
+}
+
+// Statistics of a given allocation (the collapsed sampler's initial labels,
+// collapsed_gibbs.cpp:60-63): every labelled observation counts as arriving.
+__global__ __launch_bounds__(256) void k_count_labels(ChainParams p, const int32_t* __restrict__ X,
+                                                      const int32_t* __restrict__ z, int32_t* dNk,
+                                                      int32_t* dS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool has_minus = p.mode != MODE_SB;
+    int32_t* const hist = reinterpret_cast<int32_t*>(smem);
+    const int P = p.P, K = p.K, tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < K * P + K; i += 256) hist[i] = 0;
+    __syncthreads();
+    ResampleArgs a{};
+    a.X = X; a.lo = 0; a.hi = p.N;
+    const int64_t ntiles = (p.N + 255) / 256;
+    const int nstages = (P + kStage - 1) / kStage;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TilePos pos = tile_pos(a, tile, 256, tid, lane);
+        uint32_t st[kStage], b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll 1
+        for (int h = 0; h < nstages; ++h) {
+            issue_stage(pos, p.N, P, h, st);
+            put_stage(pack_stage(P, h, st), h, b0, b1, b2, b3);
+        }
+        const int zl = z[pos.ic];
+        count_movers(pos.valid && zl >= 0, -1, zl, b0, b1, b2, b3, hist, K, P, lane);
+    }
+    __syncthreads();
+    flush_hist(hist, K, P, dS, dNk, tid, 256);
+}
+
+// Diagnostic build only (-DBMM_DIAG, never shipped): per-wave cycle stamps of the phases.
+#ifdef BMM_DIAG
+__device__ __forceinline__ unsigned long long diag_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DIAG(...) __VA_ARGS__
+#else
+#define DIAG(...)
+#endif
+
+// The z-resample kernel.  Software pipeline per wave, two levels:
+//  * HBM: while tile t is scored, the 16 loads of feature stage h of tile t+1 are in
+//    flight; they are packed after lookup group 4h+3 and the loads of stage h+1 issued;
+//  * LDS: the K lookups of a group are issued together and added as they return (volatile:
+//    one ds_read_b64 each -- the compiler would otherwise pair them into ds_read2_b64,
+//    which moves half the bytes per clock).
+// MINUS says where the own-cluster ("minus self") tables are: 0 none (stick-breaking),
+// 1 in LDS, 2 in global memory.  It is a template parameter because a possible VMEM load in
+// the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
+template <int KT, int NT, int MINUS>
+__global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
+    static_assert(KT % CH == 0, "chunking");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool has_minus = MINUS != 0;
     const TableLayout L{p.G, KT, has_minus ? 1 : 0};
     double* const lds = reinterpret_cast<double*>(smem);
-    const int lds_doubles = (has_minus && a.minus_in_lds) ? L.doubles() : L.head();
-    const double* const Tp = lds + L.tp();
-    const double* const TmL = lds + L.tm();
+    const int lds_doubles = MINUS == 1 ? L.doubles() : L.head();
+    const volatile lds_f64* const Tp = (const volatile lds_f64*)(lds + L.tp());
+    const lds_f64* const TmL = (const lds_f64*)(lds + L.tm());
     const double* const TmG = a.tab + L.tm();
     const double* const Cp = lds + L.cp();
     const double* const Cm = lds + L.cm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(lds + L.nk());
     int32_t* const hist = reinterpret_cast<int32_t*>(lds + lds_doubles);  // [K*P] then [K]
     const int P = p.P, G = p.G, K = p.K;
-    const int nhist = K * P + K;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t ntiles = (a.hi - a.lo + NT - 1) / NT;
+    const int nstages = (P + kStage - 1) / kStage;
 
-    if (!a.assign_only) {
+    int64_t tile = blockIdx.x;
+    const bool has_tile = tile < ntiles;
+    uint32_t st[kStage];
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) st[u] = 0;
+    TilePos pos = tile_pos(a, has_tile ? tile : 0, NT, tid, lane);
+    // first loads of the first tile go out before the tables are staged
+    if (has_tile) issue_stage(pos, p.N, P, 0, st);
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    {
         const double2* src = reinterpret_cast<const double2*>(a.tab);
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int i = tid; i < lds_doubles / 2; i += NT) dst[i] = src[i];
     }
-    for (int i = tid; i < nhist; i += NT) hist[i] = 0;
+    for (int i = tid; i < K * P + K; i += NT) hist[i] = 0;
     __syncthreads();
 
     // DP bookkeeping shared by the whole batch (collapsed_gibbs_dp.cpp:166-171,212-231)
     int Kused = 0, new_label = -1;
-    if (p.mode == MODE_DP && !a.assign_only) {
+    if (p.mode == MODE_DP) {
         for (int k = 0; k < K; ++k) {
             if (NkT[k] > 0) ++Kused;
             else if (new_label < 0) new_label = k;
         }
     }
 
-    const int64_t span = a.hi - a.lo;
-    const int64_t ntiles = (span + NT - 1) / NT;
-    const int nstages = (P + kStage - 1) / kStage;
-
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-        uint32_t st[kStage];
-#pragma unroll
-        for (int u = 0; u < kStage; ++u) st[u] = 0;
-        TilePos pos = tile_pos(a, tile, NT, tid, lane);
-        // prologue: the first tile's features, nothing to overlap with yet
-        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    DIAG(unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
+    if (has_tile) {
+        // prologue: the rest of the first tile's features, nothing to overlap with yet
+        put_stage(pack_stage(P, 0, st), 0, b0, b1, b2, b3);
+        // no accumulators are live yet, so four stages (64 loads) share one round trip
 #pragma unroll 1
-        for (int h = 0; h < nstages; ++h) {
-            issue_stage(pos, p.N, P, h, st);
-            put_stage(pack_stage(P, h, st), h, b0, b1, b2, b3);
+        for (int h0 = 1; h0 < nstages; h0 += 4) {
+            uint32_t s0[kStage], s1[kStage], s2[kStage], s3[kStage];
+            issue_stage(pos, p.N, P, h0, s0);
+            if (h0 + 1 < nstages) issue_stage(pos, p.N, P, h0 + 1, s1);
+            if (h0 + 2 < nstages) issue_stage(pos, p.N, P, h0 + 2, s2);
+            if (h0 + 3 < nstages) issue_stage(pos, p.N, P, h0 + 3, s3);
+            put_stage(pack_stage(P, h0, s0), h0, b0, b1, b2, b3);
+            if (h0 + 1 < nstages) put_stage(pack_stage(P, h0 + 1, s1), h0 + 1, b0, b1, b2, b3);
+            if (h0 + 2 < nstages) put_stage(pack_stage(P, h0 + 2, s2), h0 + 2, b0, b1, b2, b3);
+            if (h0 + 3 < nstages) put_stage(pack_stage(P, h0 + 3, s3), h0 + 3, b0, b1, b2, b3);
         }
         int zo = a.z_in ? a.z_in[pos.ic] : -1;
-        asm volatile("" : "+v"(zo));  // land it before the pipeline starts (see below)
+        asm volatile("" : "+v"(zo));  // land it before the pipeline starts: no load may be
+                                      // pending at a loop header (the compiler would drain
+                                      // vmcnt(0) at the first register reuse inside the loop)
+        DIAG({ const unsigned long long n_ = diag_stamp(); d_pro += n_ - d_t; d_t = n_; })
 
+        int zn_prev = 0;
+        int64_t i_prev = -1;  // < 0: nothing to store yet
         for (;;) {
+            // the previous tile's labels go out here, ahead of this iteration's stage loads in
+            // the in-order VMEM stream: a store still pending at the loop latch would make the
+            // compiler wait vmcnt(0) there, i.e. a full write round trip per tile
+            if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
             const int64_t next = tile + gridDim.x;
             const bool has_next = next < ntiles;  // uniform
             const TilePos npos = tile_pos(a, has_next ? next : tile, NT, tid, lane);
             uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             int zo_next = -1;
-            if (has_next) issue_stage(npos, p.N, P, 0, st);
             const int zoc = zo < 0 ? 0 : zo;
 
-            // ---- scoring: K * G conflict-free LDS lookups (volatile: one ds_read_b64 each;
-            // the compiler would otherwise pair them into ds_read2_b64 at half the bytes/clk).
-            // Clusters are read eight at a time so that at most 16 result registers are live.
+            // ---- scoring: K * G conflict-free LDS lookups.  One outer iteration = one feature
+            // stage: its loads for the NEXT tile are issued first, fly during the four lookup
+            // groups of THIS tile, and are packed last -- nothing in flight is loop-carried.
             double acc[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) acc[k] = 0.0;
             double acc_own = 0.0;
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
-                if (!a.assign_only) {
-                    const uint32_t word = (h >> 1) == 0 ? b0 : ((h >> 1) == 1 ? b1 : ((h >> 1) == 2 ? b2 : b3));
-                    const uint32_t half = word >> ((h & 1) * kStage);
-                    const int g_hi = G < h * 4 + 4 ? G : h * 4 + 4;
+                if (has_next) issue_stage(npos, p.N, P, h, st);
+                // the next tile's previous labels ride along with its first stage
+                if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
+                const int g_hi = G < h * 4 + 4 ? G : h * 4 + 4;
 #pragma unroll 1
-                    for (int g = h * 4; g < g_hi; ++g) {
-                        const unsigned nib = (half >> ((g & 3) * 4)) & 15u;
-                        const volatile lds_f64* row =
-                            (const volatile lds_f64*)Tp + ((size_t)g * KT * kGroupM + nib);
+                for (int g = h * 4; g < g_hi; ++g) {
+                    const unsigned nib = nibble_of(g, b0, b1, b2, b3);
+                    const volatile lds_f64* row = Tp + ((size_t)g * KT * kGroupM + nib);
+                    double own = 0.0;
+                    if (MINUS == 1) own = TmL[((size_t)g * KT + zoc) * kGroupM + nib];
+                    if (MINUS == 2) own = TmG[((size_t)g * KT + zoc) * kGroupM + nib];
 #pragma unroll
-                        for (int k0 = 0; k0 < KT; k0 += 8) {
+                    for (int c0 = 0; c0 < KT; c0 += CH) {
+                        double tv[CH];
 #pragma unroll
-                            for (int k = k0; k < (k0 + 8 < KT ? k0 + 8 : KT); ++k)
-                                acc[k] = acc[k] + row[k * kGroupM];
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        if (has_minus) {
-                            const size_t off = ((size_t)g * KT + zoc) * kGroupM + nib;
-                            double own;
-                            if (a.minus_in_lds) own = ((const lds_f64*)TmL)[off];
-                            else own = TmG[off];
-                            acc_own = acc_own + own;
-                        }
+                        for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * kGroupM];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
                     }
+                    if (has_minus) acc_own = acc_own + own;
                 }
-                if (has_next) {  // stage h of the next tile has landed by now; fetch stage h+1
-                    put_stage(pack_stage(P, h, st), h, n0, n1, n2, n3);
-                    if (h + 1 < nstages) issue_stage(npos, p.N, P, h + 1, st);
-                }
+                DIAG({ const unsigned long long n_ = diag_stamp(); d_score += n_ - d_t; d_t = n_; })
+                if (has_next) put_stage(pack_stage(P, h, st), h, n0, n1, n2, n3);
+                DIAG({ const unsigned long long n_ = diag_stamp(); d_pack += n_ - d_t; d_t = n_; })
             }
-
-            // every stage of the next tile is packed; its previous label is fetched now, with
-            // nothing else in flight, and lands during the draw below
-            if (has_next && a.z_in) zo_next = a.z_in[npos.ic];
-
-            int zn = a.assign_only ? zo : zoc;
-            if (!a.assign_only) {
-                // scores; the observation's own cluster is scored without itself
-                const double cm_own = Cm[zoc];
-                double m = neg_inf();
+            // scores; the observation's own cluster is scored without itself
+            const double cm_own = Cm[zoc];
+            double m = neg_inf();
 #pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    double sc = Cp[k] + acc[k];
-                    if (has_minus && k == zo) sc = cm_own + acc_own;
-                    acc[k] = sc;
-                    m = sc > m ? sc : m;
-                }
-                double tot = 0.0;
+            for (int k = 0; k < KT; ++k) {
+                double sc = Cp[k] + acc[k];
+                if (has_minus && k == zo) sc = cm_own + acc_own;
+                acc[k] = sc;
+                m = sc > m ? sc : m;
+            }
+            double tot = 0.0;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    const double w = exp_(acc[k] - m);
-                    acc[k] = w;
-                    tot = tot + w;
-                }
-                const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
-                const double t = u * tot;
-                double cdf = 0.0;
-                int cnt = 0, last = -1;
+            for (int k = 0; k < KT; ++k) {
+                const double w = exp_(acc[k] - m);
+                acc[k] = w;
+                tot = tot + w;
+            }
+            const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
+            const double t = u * tot;
+            double cdf = 0.0;
+            int cnt = 0, last = -1;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    cdf = cdf + acc[k];
-                    cnt += t >= cdf ? 1 : 0;
-                    last = acc[k] > 0.0 ? k : last;
-                }
-                zn = cnt < KT ? cnt : last;
-                if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
-                if (p.mode == MODE_DP && zn == K) {
-                    const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
-                    if (Kused - own_single < K - 1) {
-                        zn = new_label;
-                        if (own_single && (zn < 0 || zo < zn)) zn = zo;
-                    } else {
-                        int best = -1, bs = 0;
-                        for (int k = 0; k < K; ++k) {
-                            const int sz = NkT[k] - (k == zo ? 1 : 0);
-                            if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
-                        }
-                        zn = best >= 0 ? best : zoc;
+            for (int k = 0; k < KT; ++k) {
+                cdf = cdf + acc[k];
+                cnt += t >= cdf ? 1 : 0;
+                last = acc[k] > 0.0 ? k : last;
+            }
+            int zn = cnt < KT ? cnt : last;
+            if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
+            if (p.mode == MODE_DP && zn == K) {
+                const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
+                if (Kused - own_single < K - 1) {
+                    zn = new_label;
+                    if (own_single && (zn < 0 || zo < zn)) zn = zo;
+                } else {
+                    int best = -1, bs = 0;
+                    for (int k = 0; k < K; ++k) {
+                        const int sz = NkT[k] - (k == zo ? 1 : 0);
+                        if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
                     }
-                }
-                if (pos.valid) a.z_out[pos.i] = zn;
-            } else if (pos.valid && a.z_out != a.z_in) {
-                a.z_out[pos.i] = zo;
-            }
-
-            // statistics: one mover at a time, one feature per lane
-            const int zfrom = a.assign_only ? -1 : zo;
-            unsigned long long movers = __ballot(pos.valid && zn >= 0 && zn != zfrom);
-            while (movers) {
-                const int src = __ffsll((long long)movers) - 1;
-                movers &= movers - 1;
-                const int mzn = __builtin_amdgcn_readlane(zn, src);
-                const int mzo = __builtin_amdgcn_readlane(zfrom, src);
-                const uint32_t w0 = __builtin_amdgcn_readlane(b0, src), w1 = __builtin_amdgcn_readlane(b1, src);
-                const uint32_t w2 = __builtin_amdgcn_readlane(b2, src), w3 = __builtin_amdgcn_readlane(b3, src);
-                const uint32_t lo_w = lane < 32 ? w0 : w1, hi_w = lane < 32 ? w2 : w3;
-                const int sh = lane & 31;
-                if (lane < P && ((lo_w >> sh) & 1u)) {
-                    atomicAdd(&hist[mzn * P + lane], 1);
-                    if (mzo >= 0) atomicAdd(&hist[mzo * P + lane], -1);
-                }
-                if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
-                    atomicAdd(&hist[mzn * P + lane + 64], 1);
-                    if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
-                }
-                if (lane == 0) {
-                    atomicAdd(&hist[K * P + mzn], 1);
-                    if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
+                    zn = best >= 0 ? best : zoc;
                 }
             }
+            DIAG({ const unsigned long long n_ = diag_stamp(); d_draw += n_ - d_t; d_t = n_; })
 
+            count_movers(pos.valid && zn >= 0 && zn != zo, zo, zn, b0, b1, b2, b3, hist, K, P, lane);
+            DIAG({ const unsigned long long n_ = diag_stamp(); d_mov += n_ - d_t; d_t = n_; })
+
+            zn_prev = zn;
+            i_prev = pos.valid ? pos.i : -1;
             if (!has_next) break;
             b0 = n0; b1 = n1; b2 = n2; b3 = n3;
-            // retire the label prefetch here, while it is the only load outstanding: a wait
-            // in the next iteration would sit behind that iteration's stage loads (vmcnt is
-            // in order) and drain them
-            asm volatile("" : "+v"(zo_next));
             zo = zo_next;
             pos = npos;
             tile = next;
         }
+        if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
     }
 
     __syncthreads();
-    for (int i = tid; i < nhist; i += NT) {
-        const int32_t v = hist[i];
-        if (v != 0) {
-            if (i < K * P) atomicAdd(&a.dS[i], v);
-            else atomicAdd(&a.dNk[i - K * P], v);
-        }
-    }
+    flush_hist(hist, K, P, a.dS, a.dNk, tid, NT);
+    DIAG(if (a.diag && lane == 0) {
+        atomicAdd(&a.diag[0], d_score); atomicAdd(&a.diag[1], d_pack); atomicAdd(&a.diag[2], d_draw);
+        atomicAdd(&a.diag[3], d_mov); atomicAdd(&a.diag[4], d_pro); atomicAdd(&a.diag[5], 1ull);
+    })
 }
 
 // S x N column-major 1-based output from the [S][N] 0-based device trace (tiled transpose)
