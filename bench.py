@@ -34,7 +34,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--burn", type=int, default=30,
+                    help="untimed set-up sweeps before the warm-up, so that the timed region is the "
+                         "chain's steady state and not its first sweeps from a random allocation")
     ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5", "ns"])
     ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
@@ -48,11 +51,9 @@ def main():
     import torch.distributed as dist
 
     import bmm_mcmc_amd as bm
-    from bmm_mcmc_amd import synth
+    from bmm_mcmc_amd import multi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local = multi.world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -60,9 +61,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    multi.init("nccl", device=dev)
 
     sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
     if args.n:
@@ -73,14 +72,13 @@ def main():
         X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
     else:
         X = torch.empty((P, N), dtype=torch.int32, device=dev)
-    if world > 1:
-        dist.broadcast(X, src=0)
+    multi.broadcast_data(X, src=0)
     torch.cuda.synchronize()
 
-    batch = args.batch if args.batch > 0 else bm.default_batch(sampler, N)
-    seed = 1000 + rank  # chain seeds 1000 + c
-    ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, batch=batch, seed=seed,
-                  device=local)
+    seed = multi.chain_seed(1000, rank)  # chain seeds 1000 + c
+    ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
+                  batch=args.batch if args.batch > 0 else None, seed=seed, device=local)
+    batch = ch.batch  # the library default unless --batch was given
     ch.set_data_device(X.data_ptr(), keepalive=X)
     rng = np.random.default_rng(seed)
     if sampler == "collapsed":
@@ -94,6 +92,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ch.sweeps(args.burn)
     ch.sweeps(args.warmup)
     ch.sync()
     ch.profile(True)
@@ -107,13 +106,8 @@ def main():
     ch.profile(False)
     shape = ch.kernel_shape()
 
-    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    km = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    kern_ms = float(km.item())
+    dt = multi.max_over_ranks(t1 - t0)
+    kern_ms = multi.max_over_ranks(kern_ms)
 
     result = None
     if rank == 0:
@@ -141,6 +135,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
                        "sampler": sampler, "K": K, "N": N, "P": P, "batch": batch, "chains": world,
+                       "burn_sweeps": args.burn,
                        "x_layout": "int32 column-major (as R hands it over)",
                        "allocations_per_s": world * args.steps * N / dt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

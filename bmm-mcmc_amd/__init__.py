@@ -215,6 +215,10 @@ class Chain:
         _capi.check(_capi.lib().bmm_chain_sync(self._h))
 
     @property
+    def batch(self):
+        return int(_capi.lib().bmm_chain_batch(self._h))
+
+    @property
     def sweep_index(self):
         return int(_capi.lib().bmm_chain_sweep_index(self._h))
 

@@ -19,7 +19,7 @@ SYMBOLS = [
     "bmm_chain_set_data_device", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
     "bmm_chain_sweeps", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
     "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",
-    "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_device_math", "bmm_device_variates",
+    "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_chain_batch", "bmm_device_math", "bmm_device_variates",
     "bmm_device_count",
 ]
 
@@ -42,6 +42,8 @@ def lib():
         L.bmm_last_error.restype = C.c_char_p
         L.bmm_default_batch.restype = C.c_int64
         L.bmm_default_batch.argtypes = [C.c_int, C.c_int64]
+        L.bmm_chain_batch.restype = C.c_int64
+        L.bmm_chain_batch.argtypes = [C.c_void_p]
         L.bmm_chain_destroy.restype = None
         L.bmm_chain_destroy.argtypes = [C.c_void_p]
         _LIB = L

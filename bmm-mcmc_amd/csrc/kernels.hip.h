@@ -443,7 +443,7 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
 template <int KT, int NT, int MINUS>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
-    constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
+    constexpr int CH = KT <= 12 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
     static_assert(KT % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool has_minus = MINUS != 0;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         }
     }
 
-    DIAG(unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
+    DIAG(unsigned long long d_nmov = 0, d_ntile = 0; unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
     if (has_tile) {
         // prologue: the rest of the first tile's features, nothing to overlap with yet
         put_stage(pack_stage(P, 0, st), 0, b0, b1, b2, b3);
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                         for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * kGroupM];
 #pragma unroll
                         for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
+                        if (CH < KT) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
                     }
                     if (has_minus) acc_own = acc_own + own;
                 }
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 const double w = exp_(acc[k] - m);
                 acc[k] = w;
                 tot = tot + w;
+                if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries
             }
             const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
             const double t = u * tot;
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             }
             DIAG({ const unsigned long long n_ = diag_stamp(); d_draw += n_ - d_t; d_t = n_; })
 
+            DIAG(d_nmov += __popcll(__ballot(pos.valid && zn >= 0 && zn != zo));)
             count_movers(pos.valid && zn >= 0 && zn != zo, zo, zn, b0, b1, b2, b3, hist, K, P, lane);
             DIAG({ const unsigned long long n_ = diag_stamp(); d_mov += n_ - d_t; d_t = n_; })
 
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     DIAG(if (a.diag && lane == 0) {
         atomicAdd(&a.diag[0], d_score); atomicAdd(&a.diag[1], d_pack); atomicAdd(&a.diag[2], d_draw);
         atomicAdd(&a.diag[3], d_mov); atomicAdd(&a.diag[4], d_pro); atomicAdd(&a.diag[5], 1ull);
+        atomicAdd(&a.diag[6], d_nmov);
     })
 }
 

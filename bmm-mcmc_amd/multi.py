@@ -1,0 +1,103 @@
+"""One independent MCMC chain per GPU of a node.
+
+The path shards across chains, not within one: every rank holds a full replica of the data
+matrix and runs its own chain, so there is exactly one collective on the data path -- the
+one-off broadcast of X from rank 0 (RCCL over xGMI with the "nccl" backend) -- plus an
+optional gather of small per-chain summaries at the end.  Launch one process per GPU
+(`python -m torch.distributed.run --nproc-per-node N ...`).
+
+torch is plumbing here (process group, device tensors).  The chain itself is the HIP path
+(bmm_mcmc_amd.Chain); `run_fn` lets the multi-process CPU tests drive the same plumbing
+over gloo with a checker of their own.
+"""
+import os
+
+import numpy as np
+
+
+def world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(
+        os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None, device=None):
+    """Join the process group if launched with more than one rank.  Returns (world, rank, local)."""
+    import torch.distributed as dist
+    w, r, l = world()
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            import torch
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return w, r, l
+
+
+def chain_seed(base, rank):
+    """Chain c of a job gets Philox key base + c (chains are independent streams)."""
+    return (int(base) + int(rank)) & 0xFFFFFFFFFFFFFFFF
+
+
+def broadcast_data(X, src=0):
+    """Broadcast the (P, N) int32 tensor X (= N x P column-major) from `src` to every rank, in place."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(X, src=src)
+    return X
+
+
+def gather_summaries(vec):
+    """All-gather one small float64 vector per chain; returns a (world, len) array on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.float64))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.numpy()[None, :]
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()
+
+
+def max_over_ranks(x):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_chains(sampler, X, K, nsweeps, base_seed=1000, batch=None, run_fn=None, **prior):
+    """Run one chain on this rank over the (already broadcast) data and gather the sorted
+    cluster proportions of every chain.  `run_fn(sampler, X, K, nsweeps, seed, batch, **prior)`
+    must return final 1-based labels; the default is the HIP chain on this rank's GPU."""
+    w, r, l = world()
+    seed = chain_seed(base_seed, r)
+    if run_fn is None:
+        run_fn = _hip_chain
+    z = np.asarray(run_fn(sampler, X, K, nsweeps, seed, batch, **prior))
+    props = np.sort(np.bincount(z[z > 0] - 1, minlength=K)[:K] / max(1, (z > 0).sum()))[::-1]
+    return z, gather_summaries(props)
+
+
+def _hip_chain(sampler, X, K, nsweeps, seed, batch, **prior):
+    from . import Chain
+    w, r, l = world()
+    P, N = X.shape
+    with Chain(sampler, N, P, K, batch=batch, seed=seed, device=l, **prior) as ch:
+        ch.set_data_device(X.data_ptr(), keepalive=X)
+        rng = np.random.default_rng(seed)
+        if sampler == "collapsed":
+            ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+        elif sampler == "stickbreaking":
+            pi0 = np.exp(rng.random(K))
+            ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+        ch.sweeps(nsweeps)
+        return ch.labels()

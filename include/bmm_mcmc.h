@@ -48,7 +48,8 @@ extern "C" {
 const char* bmm_last_error(void);
 /* features per lookup group of the spec arithmetic (DESIGN.md "Numerics") */
 int bmm_spec_group_width(void);
-/* library default batch size for N observations (used when batch <= 0) */
+/* library default batch size for N observations (used when batch <= 0): N/8 for the finite
+ * sampler, N/16 for the DP sampler, N for stick-breaking; see DESIGN.md "Batches" */
 int64_t bmm_default_batch(int sampler, int64_t N);
 
 /* ---- drop-in entry points --------------------------------------------------------
@@ -101,6 +102,8 @@ int bmm_chain_get_params(bmm_chain* c, double* pi /*K*/, double* theta /*K x P c
  * sweeps, sync, read total milliseconds and launch count since it was turned on */
 int bmm_chain_profile(bmm_chain* c, int enable);
 int bmm_chain_profile_read(bmm_chain* c, double* resample_ms, int64_t* resample_launches);
+/* batch size in effect (a defaulted one is rounded up to whole rounds of workgroups) */
+int64_t bmm_chain_batch(const bmm_chain* c);
 /* bytes of dynamic LDS and threads per workgroup the resample kernel uses for this shape */
 int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int* grid_max);
 

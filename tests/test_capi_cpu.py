@@ -35,7 +35,8 @@ def test_spec_constants_match_oracle(oracle):
 def test_default_batch_policy():
     assert bm.default_batch("stickbreaking", 1000) == 1000
     assert bm.default_batch("collapsed", 100) == 12
-    assert bm.default_batch("collapsed", 10 ** 7) == 1 << 20
+    assert bm.default_batch("collapsed", 10 ** 7) == 1250000
+    assert bm.default_batch("dp", 1600) == 100
     assert bm.default_batch("dp", 3) == 1
 
 

@@ -1,0 +1,84 @@
+"""The one-chain-per-rank plumbing (bmm_mcmc_amd.multi) over gloo, world size 2, on CPU:
+broadcast of the data matrix, per-rank seeds, gather of per-chain summaries.  The compute is
+injected (the oracle stands in as the checker here); on a GPU node the default is the HIP chain."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_chain(sampler, X, K, nsweeps, seed, batch, **prior):
+    from oracle import oracle
+    Xh = np.asfortranarray(X.t().numpy())
+    z0 = np.random.default_rng(seed).integers(1, K + 1, Xh.shape[0]).astype(np.int32)
+    r = oracle.collapsed(Xh, z0, nsweeps + 1, K, 0.0, 0.5, 0.5, 1, 1, nsweeps, seed=seed, batch=batch or 1)
+    return r["z"][0]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from bmm_mcmc_amd import multi
+    from util import synth
+    w, r, l = multi.init(backend="gloo")
+    assert (w, r) == (world, rank)
+    P, N, K = 8, 600, 3
+    if rank == 0:
+        Xh, _, _, _ = synth(N, P, K, 18)
+        X = torch.from_numpy(np.ascontiguousarray(Xh.T))  # (P, N) = N x P column-major
+    else:
+        X = torch.zeros((P, N), dtype=torch.int32)
+    multi.broadcast_data(X, src=0)
+    z, summ = multi.run_chains("collapsed", X, K, 30, base_seed=1000, batch=64, run_fn=_oracle_chain)
+    z_same, _ = multi.run_chains("collapsed", X, K, 30, base_seed=1000, batch=64, run_fn=_oracle_chain)
+    mx = multi.max_over_ranks(1.0 + rank)
+    q.put((rank, int(X.sum()), z.tolist(), z_same.tolist(), summ.tolist(), mx, multi.chain_seed(1000, rank)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_broadcast_seed_and_gather(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, sum0, z0, z0b, summ0, mx0, seed0), (r1, sum1, z1, z1b, summ1, mx1, seed1) = got
+    assert sum0 == sum1 and sum0 > 0            # every rank holds the broadcast matrix
+    assert (seed0, seed1) == (1000, 1001)       # chain c runs under key base + c
+    assert z0 == z0b and z1 == z1b              # same seed -> same chain
+    assert z0 != z1                             # different seeds -> different chains
+    assert summ0 == summ1 and len(summ0) == 2   # all ranks see every chain's summary, in rank order
+    np.testing.assert_allclose(np.sum(summ0, axis=1), 1.0)
+    assert all(a >= b for a, b in zip(summ0[0], summ0[0][1:]))  # sorted proportions
+    assert mx0 == mx1 == 2.0
+
+
+def test_single_process_helpers_need_no_group():
+    from bmm_mcmc_amd import multi
+    assert multi.world() == (1, 0, 0) or multi.world()[0] >= 1
+    assert multi.max_over_ranks(3.5) == 3.5
+    assert multi.gather_summaries([0.25, 0.75]).tolist() == [[0.25, 0.75]]
+    assert multi.chain_seed(2 ** 64 - 1, 2) == 1
