@@ -44,3 +44,19 @@ gibbs_stickbreaking <- function(data, nsamples, maxK, alpha=NULL, beta=0.5, gamm
           nsamples, maxK, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug,
           as.numeric(.bmm_seed(seed)))
 }
+
+gibbs_full <- function(data, nsamples, K, alpha=NULL, beta=0.5, gamma=0.5,
+                       a=1, b=1,
+                       burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE, seed=NULL) {
+    if (is.null(burnin)) burnin <- round(0.1 * nsamples)
+    initial_pi <- stats::runif(K)
+    initial_pi <- exp(initial_pi)
+    initial_pi <- initial_pi / sum(initial_pi)
+    if (is.null(alpha)) alpha <- 0
+    if (burnrelabel > burnin) burnrelabel <- round(0.1 * burnin)
+    initial_theta <- matrix(stats::runif(K*ncol(data)), ncol=ncol(data), nrow=K)
+    storage.mode(data) <- "integer"
+    .Call('_bmmmcmc_gibbs_cpp', PACKAGE = 'bmmmcmc', data, initial_pi, initial_theta,
+          nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug,
+          as.numeric(.bmm_seed(seed)))
+}

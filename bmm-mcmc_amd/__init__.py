@@ -17,7 +17,7 @@ import numpy as _np
 from . import _capi
 from ._capi import BmmError, NA_INTEGER
 
-__all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "Chain", "BmmError", "NA_INTEGER",
+__all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
            "default_batch"]
 
 
@@ -51,8 +51,7 @@ def _na_perm(S, K):
 
 
 def default_batch(sampler, N):
-    code = {"collapsed": 0, "dp": 1, "stickbreaking": 2}[sampler]
-    return int(_capi.lib().bmm_default_batch(code, N))
+    return int(_capi.lib().bmm_default_batch(_capi.SAMPLER_CODE[sampler], N))
 
 
 def gibbs_collapsed(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None,
@@ -148,11 +147,44 @@ def gibbs_stickbreaking(data, nsamples, maxK, alpha=None, beta=0.5, gamma=0.5, a
     return {"pi": pi, "alpha": al, "permutations": _na_perm(S, maxK), "z": z, "theta": theta}
 
 
+def gibbs_full(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None, relabel=False,
+               burnrelabel=50, debug=False, *, seed=None, device=0, initial_pi=None, initial_theta=None):
+    """Full (uncollapsed) Gibbs sampler, finite K (R/utils.R:64-78 -> src/full_gibbs.cpp:32)."""
+    _no_relabel(relabel)
+    X = _capi.as_x(data)
+    N, P = X.shape
+    nsamples, K = int(nsamples), int(K)
+    burnin = _burnin(burnin, nsamples)
+    seed = _seed(seed)
+    rng = _np.random.default_rng(seed)
+    if initial_pi is None:  # R/utils.R:68-70
+        initial_pi = _np.exp(rng.random(K))
+        initial_pi = initial_pi / initial_pi.sum()
+    if initial_theta is None:  # R/utils.R:74
+        initial_theta = rng.random(K * P).reshape((K, P), order="F")
+    pi0 = _np.ascontiguousarray(initial_pi, dtype=_np.float64)
+    th0 = _np.asfortranarray(initial_theta, dtype=_np.float64)
+    if pi0.shape != (K,) or th0.shape != (K, P):
+        raise ValueError("initial_pi must have K entries and initial_theta be K x P")
+    S = nsamples - burnin
+    z = _np.zeros((S, N), dtype=_np.int32, order="F")
+    theta = _np.zeros((K, P, S), order="F")
+    al = _np.zeros((S, 1), order="F")
+    pi = _np.zeros((S, K), order="F")
+    rc = _capi.lib().bmm_full_run(
+        _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(pi0), _capi.vp(th0), _C.c_int(nsamples),
+        _C.c_int(K), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
+        _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed), _C.c_int(device),
+        _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al))
+    _capi.check(rc)
+    return {"pi": pi, "alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
+
+
 class Chain:
     """One chain resident on one GPU (bmm_chain_* in include/bmm_mcmc.h): the data matrix
     and the chain state stay in HBM between `sweeps()` calls."""
 
-    _CODE = {"collapsed": 0, "dp": 1, "stickbreaking": 2}
+    _CODE = _capi.SAMPLER_CODE
 
     def __init__(self, sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, batch=None, seed=0,
                  device=0):

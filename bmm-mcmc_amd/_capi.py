@@ -9,13 +9,14 @@ from . import build as _build
 
 _LIB = None
 
-SAMPLER_COLLAPSED, SAMPLER_DP, SAMPLER_SB = 0, 1, 2
+SAMPLER_COLLAPSED, SAMPLER_DP, SAMPLER_SB, SAMPLER_FULL = 0, 1, 2, 3
+SAMPLER_CODE = {"collapsed": 0, "dp": 1, "stickbreaking": 2, "full": 3}
 NA_INTEGER = -2147483648
 
 # every symbol include/bmm_mcmc.h declares
 SYMBOLS = [
     "bmm_last_error", "bmm_spec_group_width", "bmm_default_batch", "bmm_collapsed_run", "bmm_dp_run",
-    "bmm_sb_run", "bmm_chain_create", "bmm_chain_destroy", "bmm_chain_set_data_host",
+    "bmm_sb_run", "bmm_full_run", "bmm_chain_create", "bmm_chain_destroy", "bmm_chain_set_data_host",
     "bmm_chain_set_data_device", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
     "bmm_chain_sweeps", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
     "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",

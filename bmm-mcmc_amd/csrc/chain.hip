@@ -117,13 +117,13 @@ namespace {
 // (no measurable shift at any batch on well-separated data); the DP sampler opens spurious
 // clusters above about N/16, because every "new" draw of a batch shares one label.
 int64_t default_batch(int sampler, int64_t N) {
-    if (sampler == BMM_SAMPLER_SB) return N;
+    if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
     int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
     return b < 1 ? 1 : b;
 }
 
 TableLayout layout_of(const bmm_chain* c) {
-    return TableLayout{c->p.G, c->p.KT, c->p.mode != MODE_SB ? 1 : 0};
+    return TableLayout{c->p.G, c->p.KT, !explicit_params(c->p.mode) ? 1 : 0};
 }
 
 int32_t* label_row(bmm_chain* c, int j) {
@@ -203,7 +203,7 @@ int enqueue_sweep(bmm_chain* c, int j) {
     const int s = j - c->burnin;
     double* th_tr = rec ? c->dThetaTrace + (size_t)s * p.K * p.P : nullptr;
     double* al_tr = rec ? c->dAlphaTrace + s : nullptr;
-    if (p.mode == MODE_SB) {
+    if (explicit_params(p.mode)) {
         int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
@@ -254,7 +254,7 @@ int chain_start(bmm_chain* c) {
         hipLaunchKernelGGL(k_count_labels, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), hb, c->stream, p,
                            c->dX, row0, c->dDNk, c->dDS);
         HIP_TRY(hipGetLastError());
-    } else if (p.mode == MODE_SB) {
+    } else if (explicit_params(p.mode)) {
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
                            c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab);
         HIP_TRY(hipGetLastError());
@@ -292,7 +292,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
                      double gamma, double a, double b, int64_t batch, uint64_t seed, int device) {
     if (!out) return set_err(BMM_E_ARG, "out is null");
     *out = nullptr;
-    if (sampler < 0 || sampler > 2) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
+    if (sampler < 0 || sampler > 3) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
     int rc = check_common(N, P, K, beta, gamma);
     if (rc) return rc;
     if (sampler == BMM_SAMPLER_DP && beta != gamma)  // collapsed_gibbs_dp.cpp:48-50
@@ -315,7 +315,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     c->alpha0 = p.sample_alpha ? 1.0 : alpha;
     c->device = device;
     c->batch = batch <= 0 ? default_batch(sampler, N) : (batch > N ? N : batch);
-    if (sampler == BMM_SAMPLER_SB) c->batch = N;
+    if (explicit_params(sampler)) c->batch = N;
     if (p.KT < 0) {
         delete c;
         return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build tabulates on chip", p.Kc, kMaxCats);
@@ -326,7 +326,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
-    if (c->lds_bytes > lds_max && p.mode != MODE_SB) {  // second tier: own-cluster tables stay in L2
+    if (c->lds_bytes > lds_max && !explicit_params(p.mode)) {  // second tier: own-cluster tables stay in L2
         c->minus_in_lds = 0;
         c->lds_bytes = (size_t)layout_of(c).head() * sizeof(double) + hist_bytes;
     }
@@ -335,7 +335,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         delete c;
         return set_err(BMM_E_UNSUPPORTED, "K = %d, P = %d need %zu bytes of LDS tables; the CU has %zu", K, P, need, lds_max);
     }
-    c->fn = resample_kernel(p.KT, p.mode == MODE_SB ? 0 : (c->minus_in_lds ? 1 : 2));
+    c->fn = resample_kernel(p.KT, explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2));
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -345,7 +345,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
     if (per_cu < 1) per_cu = 1;
     c->grid_max = per_cu * prop.multiProcessorCount;
-    if (batch <= 0 && sampler != BMM_SAMPLER_SB) {
+    if (batch <= 0 && !explicit_params(sampler)) {
         // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
         const int64_t round = (int64_t)c->grid_max * c->NT;
         if (c->batch > round) c->batch = (c->batch + round - 1) / round * round;
@@ -427,7 +427,7 @@ int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1) {
 
 int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* theta) {
     if (!c || !pi || !theta) return set_err(BMM_E_ARG, "null argument");
-    if (c->p.mode != MODE_SB) return set_err(BMM_E_STATE, "only the stick-breaking sampler takes initial pi/theta");
+    if (!explicit_params(c->p.mode)) return set_err(BMM_E_STATE, "only the stick-breaking and full samplers take initial pi/theta");
     if (c->started) return set_err(BMM_E_STATE, "chain already started");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->dPi, pi, (size_t)c->p.K * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -503,7 +503,7 @@ int bmm_chain_get_alpha(bmm_chain* c, double* alpha) {
 
 int bmm_chain_get_params(bmm_chain* c, double* pi, double* theta) {
     if (!c || !pi || !theta) return set_err(BMM_E_ARG, "null argument");
-    if (c->p.mode != MODE_SB) return set_err(BMM_E_STATE, "only the stick-breaking sampler carries pi/theta");
+    if (!explicit_params(c->p.mode)) return set_err(BMM_E_STATE, "only the stick-breaking and full samplers carry pi/theta");
     int rc = bmm_chain_sync(c);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(pi, c->dPi, (size_t)c->p.K * sizeof(double), hipMemcpyDeviceToHost));
@@ -561,20 +561,20 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0
     HIP_TRY(hipMalloc(&c->dTrace, (size_t)S * N * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->dThetaTrace, (size_t)S * K * P * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dAlphaTrace, (size_t)S * sizeof(double)));
-    if (sampler == BMM_SAMPLER_SB) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
+    if (explicit_params(sampler)) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
     rc = bmm_chain_set_data_host(c, X);
     if (rc) return rc;
     if (sampler == BMM_SAMPLER_COLLAPSED) rc = bmm_chain_set_initial_labels(c, z0);
-    if (sampler == BMM_SAMPLER_SB) rc = bmm_chain_set_initial_params(c, pi0, theta0);
+    if (explicit_params(sampler)) rc = bmm_chain_set_initial_params(c, pi0, theta0);
     if (rc) return rc;
     if (burnin == 0) {
         // trace row 0 (DESIGN.md "Quirks"): labels = initial allocation or unassigned (-1 -> NA),
         // theta = NaN (collapsed, never written), 0 (dp, zero-filled) or the initial theta (sb)
         std::vector<double> t0((size_t)K * P, sampler == BMM_SAMPLER_DP ? 0.0 : std::nan(""));
-        if (sampler == BMM_SAMPLER_SB) std::memcpy(t0.data(), theta0, t0.size() * sizeof(double));
+        if (explicit_params(sampler)) std::memcpy(t0.data(), theta0, t0.size() * sizeof(double));
         HIP_TRY(hipMemcpy(c->dThetaTrace, t0.data(), t0.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->dAlphaTrace, &c->alpha0, sizeof(double), hipMemcpyHostToDevice));
-        if (sampler == BMM_SAMPLER_SB)
+        if (explicit_params(sampler))
             HIP_TRY(hipMemcpy2D(c->dPiTrace, (size_t)S * sizeof(double), pi0, sizeof(double), sizeof(double), K, hipMemcpyHostToDevice));
         if (sampler != BMM_SAMPLER_COLLAPSED) HIP_TRY(hipMemset(c->dTrace, 0xff, (size_t)N * sizeof(int32_t)));
     }
@@ -590,7 +590,7 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0
     HIP_TRY(hipMemcpyAsync(z_out, dOut, (size_t)S * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(theta_out, c->dThetaTrace, (size_t)S * K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(alpha_out, c->dAlphaTrace, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (sampler == BMM_SAMPLER_SB)
+    if (explicit_params(sampler))
         HIP_TRY(hipMemcpyAsync(pi_out, c->dPiTrace, (size_t)S * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
@@ -622,6 +622,15 @@ int bmm_sb_run(const int32_t* X, int64_t N, int P, const double* initialPi, cons
                double* alpha_out) {
     if (!initialPi || !initialTheta || !pi_out) return set_err(BMM_E_ARG, "null buffer");
     return run_chain(BMM_SAMPLER_SB, X, N, P, nullptr, initialPi, initialTheta, nsamples, maxK, alpha, beta,
+                     gamma, a, b, burnin, 0, seed, device, pi_out, z_out, theta_out, alpha_out);
+}
+
+int bmm_full_run(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
+                 int nsamples, int K, double alpha, double beta, double gamma, double a, double b, int burnin,
+                 uint64_t seed, int device, double* pi_out, int32_t* z_out, double* theta_out,
+                 double* alpha_out) {
+    if (!initialPi || !initialTheta || !pi_out) return set_err(BMM_E_ARG, "null buffer");
+    return run_chain(BMM_SAMPLER_FULL, X, N, P, nullptr, initialPi, initialTheta, nsamples, K, alpha, beta,
                      gamma, a, b, burnin, 0, seed, device, pi_out, z_out, theta_out, alpha_out);
 }
 

@@ -31,7 +31,9 @@ typedef __attribute__((address_space(3))) double lds_f64;  // LDS-qualified, kee
 constexpr int kMaxP = 128;      // 4 bit-words per observation
 constexpr int kMaxCats = 64;    // clusters (+ the DP's new-cluster option)
 
-enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2 };
+enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2, MODE_FULL = 3 };
+// the two samplers that carry explicit (pi, theta) and resample z | pi, theta in one exact batch
+__host__ __device__ inline bool explicit_params(int mode) { return mode == MODE_SB || mode == MODE_FULL; }
 
 // Layout of the table image in global memory, in doubles:
 //   Tp  [G][KT][16]   group tables against the full statistics
@@ -205,23 +207,39 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     __syncthreads();
     const double alpha_prev = *alpha_ptr;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        int64_t prev = 0;
-        for (int l = k + 1; l < K; ++l) prev += ck[l];
         Stream sa = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickA);
-        Stream sb = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickB);
-        v[k] = rbeta_(1.0 + (double)ck[k], alpha_prev + (double)prev, sa, sb);
+        if (p.mode == MODE_FULL) {
+            // pi ~ Dirichlet(alpha/K + c_k) through gammas (full_gibbs.cpp:10-27, 203-210)
+            v[k] = rgamma_(div_(alpha_prev, (double)K) + (double)ck[k], sa);
+        } else {
+            int64_t prev = 0;
+            for (int l = k + 1; l < K; ++l) prev += ck[l];
+            Stream sb = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickB);
+            v[k] = rbeta_(1.0 + (double)ck[k], alpha_prev + (double)prev, sa, sb);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        v[K - 1] = 1.0;
         int viable = 0;
-        double cumprod = 1.0;
-        for (int k = 0; k < K; ++k) {
-            const double pk = k == 0 ? v[0] : cumprod * v[k];
-            if (pk > 0.01) ++viable;
-            cumprod = k == 0 ? 1.0 - v[0] : cumprod * (1.0 - v[k]);
-            pi[k] = pk;
-            if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
+        if (p.mode == MODE_FULL) {
+            double sum_term = 0.0;
+            for (int k = 0; k < K; ++k) sum_term = sum_term + v[k];
+            for (int k = 0; k < K; ++k) {
+                const double pk = div_(v[k], sum_term);
+                pi[k] = pk;
+                if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
+            }
+            viable = K;  // update_alpha(..., N, K) at full_gibbs.cpp:228-230
+        } else {
+            v[K - 1] = 1.0;
+            double cumprod = 1.0;
+            for (int k = 0; k < K; ++k) {
+                const double pk = k == 0 ? v[0] : cumprod * v[k];
+                if (pk > 0.01) ++viable;
+                cumprod = k == 0 ? 1.0 - v[0] : cumprod * (1.0 - v[k]);
+                pi[k] = pk;
+                if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
+            }
         }
         double alpha_new = alpha_prev;
         if (p.sample_alpha) {

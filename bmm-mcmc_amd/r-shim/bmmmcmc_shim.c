@@ -104,11 +104,11 @@ SEXP _bmmmcmc_collapsed_gibbs_dp_cpp(SEXP df, SEXP nsamples, SEXP alpha, SEXP be
     return out;
 }
 
-/* gibbs_stickbreaking_cpp(df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b,
- *                         burnin, relabel, burnrelabel, debug [, seed]) */
-SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
-                                      SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
-                                      SEXP relabel, SEXP burnrelabel, SEXP debug, SEXP seed) {
+/* gibbs_stickbreaking_cpp / gibbs_cpp (df, initialPi, initialTheta, nsamples, maxK or K, alpha, beta,
+ *                         gamma, a, b, burnin, relabel, burnrelabel, debug [, seed]) */
+static SEXP explicit_params_run(int full, SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
+                                SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
+                                SEXP relabel, SEXP burnrelabel, SEXP debug, SEXP seed) {
     need_int_matrix(df);
     no_relabel(relabel);
     const int N = nrows(df), P = ncols(df), ns = asInteger(nsamples), k = asInteger(maxK), bi = asInteger(burnin);
@@ -118,9 +118,10 @@ SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta
     if (XLENGTH(pi0) != k || XLENGTH(th0) != (R_xlen_t)k * P) { UNPROTECT(2); error("initialPi/initialTheta have the wrong size"); }
     SEXP z = PROTECT(allocMatrix(INTSXP, S, N)), th = PROTECT(cube(k, P, S)), al = PROTECT(allocMatrix(REALSXP, S, 1));
     SEXP pi = PROTECT(allocMatrix(REALSXP, S, k));
-    const int rc = bmm_sb_run(INTEGER(df), N, P, REAL(pi0), REAL(th0), ns, k, asReal(alpha), asReal(beta),
-                              asReal(gamma), asReal(a), asReal(b), bi, (uint64_t)asReal(seed), 0, REAL(pi),
-                              INTEGER(z), REAL(th), REAL(al));
+    const int rc = (full ? bmm_full_run : bmm_sb_run)(INTEGER(df), N, P, REAL(pi0), REAL(th0), ns, k, asReal(alpha),
+                                                      asReal(beta), asReal(gamma), asReal(a), asReal(b), bi,
+                                                      (uint64_t)asReal(seed), 0, REAL(pi), INTEGER(z), REAL(th),
+                                                      REAL(al));
     if (rc) { UNPROTECT(6); error("%s", bmm_last_error()); }
     SEXP pm = PROTECT(na_perm(S, k));
     const char* nm[] = {"pi", "alpha", "permutations", "z", "theta"};
@@ -130,10 +131,25 @@ SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta
     return out;
 }
 
+SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
+                                      SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
+                                      SEXP relabel, SEXP burnrelabel, SEXP debug, SEXP seed) {
+    return explicit_params_run(0, df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
+                               relabel, burnrelabel, debug, seed);
+}
+/* gibbs_cpp, src/full_gibbs.cpp:32 */
+SEXP _bmmmcmc_gibbs_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha,
+                        SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
+                        SEXP debug, SEXP seed) {
+    return explicit_params_run(1, df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin,
+                               relabel, burnrelabel, debug, seed);
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"_bmmmcmc_collapsed_gibbs_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_cpp, 15},
     {"_bmmmcmc_collapsed_gibbs_dp_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_dp_cpp, 14},
     {"_bmmmcmc_gibbs_stickbreaking_cpp", (DL_FUNC)&_bmmmcmc_gibbs_stickbreaking_cpp, 15},
+    {"_bmmmcmc_gibbs_cpp", (DL_FUNC)&_bmmmcmc_gibbs_cpp, 15},
     {NULL, NULL, 0}};
 
 void R_init_bmmmcmc(DllInfo* dll) {

@@ -42,6 +42,7 @@ extern "C" {
 #define BMM_SAMPLER_COLLAPSED 0
 #define BMM_SAMPLER_DP 1
 #define BMM_SAMPLER_SB 2
+#define BMM_SAMPLER_FULL 3
 
 #define BMM_NA_INTEGER (-2147483647 - 1)
 
@@ -71,6 +72,14 @@ int bmm_sb_run(const int32_t* X, int64_t N, int P, const double* initialPi,
                const double* initialTheta, int nsamples, int maxK, double alpha, double beta,
                double gamma, double a, double b, int burnin, uint64_t seed, int device,
                double* pi_out, int32_t* z_out, double* theta_out, double* alpha_out);
+
+/* Replaces gibbs_cpp, the uncollapsed finite sampler (src/full_gibbs.cpp:32-45; .Call symbol
+ * _bmmmcmc_gibbs_cpp, src/RcppExports.cpp:66-88): the z-step of the stick-breaking sampler with
+ * pi ~ Dirichlet(alpha/K + counts) (full_gibbs.cpp:203-210).  SURVEY.md section 8 row f1. */
+int bmm_full_run(const int32_t* X, int64_t N, int P, const double* initialPi,
+                 const double* initialTheta, int nsamples, int K, double alpha, double beta,
+                 double gamma, double a, double b, int burnin, uint64_t seed, int device,
+                 double* pi_out, int32_t* z_out, double* theta_out, double* alpha_out);
 
 /* ---- resident chains --------------------------------------------------------------
  * The same samplers with the data matrix and the chain state kept in HBM between

@@ -628,11 +628,22 @@ int oracle_dp_literal(const int32_t* X, int64_t N, int P, int nsamples, double a
 }
 
 /* parameter draws shared by the two stick-breaking restatements (stickbreaking.cpp:164-235) */
-static void sb_draw_params(int maxK, int P, const int32_t* ck, const int32_t* Vkd /*k*P+d*/,
+static void sb_draw_params(int full, int maxK, int P, const int32_t* ck, const int32_t* Vkd /*k*P+d*/,
                            double alpha_prev, double beta, double gamma, uint64_t seed, uint32_t j,
                            double* pi, double* theta /*maxK x P colmajor*/, int* K_viable) {
     double* v = (double*)malloc(sizeof(double) * maxK);
     int64_t num_previous_clusters = 0;
+    if (full) { /* full_gibbs.cpp:203-210 with rdirichlet_cpp :10-27 */
+        double sum_term = 0;
+        for (int k = 0; k < maxK; ++k) {
+            double dirich = (alpha_prev / maxK) + ck[k];
+            v[k] = oracle_rgamma(dirich, seed, (uint32_t)k, j, 1);
+            sum_term += v[k];
+        }
+        for (int k = 0; k < maxK; ++k) pi[k] = v[k] / sum_term;
+        *K_viable = maxK; /* update_alpha(..., N, K), full_gibbs.cpp:228-230 */
+        goto thetas;
+    }
     for (int k = maxK - 1; k >= 0; --k) { /* :170-194 */
         double beta1 = 1 + ck[k];
         double beta2 = alpha_prev + (double)num_previous_clusters;
@@ -650,8 +661,9 @@ static void sb_draw_params(int maxK, int P, const int32_t* ck, const int32_t* Vk
         cumprod *= (1 - v[k]);
     }
     *K_viable = kv;
+thetas:
     for (int k = 0; k < maxK; ++k)
-        for (int d = 0; d < P; ++d) { /* :217-229 */
+        for (int d = 0; d < P; ++d) { /* stickbreaking.cpp:217-229, full_gibbs.cpp:213-226 */
             int32_t V = Vkd[(size_t)k * P + d];
             uint32_t c0 = (uint32_t)((size_t)k * P + d);
             theta[k + (size_t)d * maxK] =
@@ -660,7 +672,7 @@ static void sb_draw_params(int maxK, int P, const int32_t* ck, const int32_t* Vk
     free(v);
 }
 
-static int sb_common(int literal, const int32_t* X, int64_t N, int P, const double* pi0,
+static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, const double* pi0,
                      const double* theta0, int nsamples, int maxK, double alpha, double beta,
                      double gamma, double a, double b, int burnin, uint64_t seed, double* pi_out,
                      int32_t* z_out, double* theta_out, double* alpha_out) {
@@ -728,7 +740,7 @@ static int sb_common(int literal, const int32_t* X, int64_t N, int P, const doub
             for (int d = 0; d < P; ++d) Vkd[(size_t)k * P + d] += X[i + (size_t)d * N] & 1;
         }
         int K_viable;
-        sb_draw_params(maxK, P, ck, Vkd, alpha_sampled[j - 1], beta, gamma, seed, (uint32_t)j, pi, theta, &K_viable);
+        sb_draw_params(full, maxK, P, ck, Vkd, alpha_sampled[j - 1], beta, gamma, seed, (uint32_t)j, pi, theta, &K_viable);
         if (alpha == 0) /* :233-235 */
             alpha_sampled[j] = oracle_update_alpha(alpha_sampled[j - 1], a, b, (double)N, K_viable, seed, (uint32_t)j);
         if (j >= burnin) {
@@ -748,14 +760,30 @@ int oracle_sb_literal(const int32_t* X, int64_t N, int P, const double* pi0, con
                       int nsamples, int maxK, double alpha, double beta, double gamma, double a,
                       double b, int burnin, uint64_t seed, double* pi_out, int32_t* z_out,
                       double* theta_out, double* alpha_out) {
-    return sb_common(1, X, N, P, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed,
+    return sb_common(1, 0, X, N, P, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed,
                      pi_out, z_out, theta_out, alpha_out);
 }
 int oracle_sb_run(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
                   int nsamples, int maxK, double alpha, double beta, double gamma, double a, double b,
                   int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
                   double* alpha_out) {
-    return sb_common(0, X, N, P, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed,
+    return sb_common(0, 0, X, N, P, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed,
+                     pi_out, z_out, theta_out, alpha_out);
+}
+
+/* full_gibbs.cpp:32-249 (gibbs_cpp): the z-step is stickbreaking.cpp's with K for maxK */
+int oracle_full_literal(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                        int nsamples, int K, double alpha, double beta, double gamma, double a, double b,
+                        int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
+                        double* alpha_out) {
+    return sb_common(1, 1, X, N, P, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed,
+                     pi_out, z_out, theta_out, alpha_out);
+}
+int oracle_full_run(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                    int nsamples, int K, double alpha, double beta, double gamma, double a, double b,
+                    int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
+                    double* alpha_out) {
+    return sb_common(0, 1, X, N, P, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed,
                      pi_out, z_out, theta_out, alpha_out);
 }
 

@@ -95,6 +95,15 @@ int oracle_sb_run(const int32_t* X, int64_t N, int P, const double* pi0, const d
                   int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
                   double* alpha_out);
 
+int oracle_full_literal(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                        int nsamples, int K, double alpha, double beta, double gamma, double a, double b,
+                        int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
+                        double* alpha_out);
+int oracle_full_run(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
+                    int nsamples, int K, double alpha, double beta, double gamma, double a, double b,
+                    int burnin, uint64_t seed, double* pi_out, int32_t* z_out, double* theta_out,
+                    double* alpha_out);
+
 /* ---- CPU baseline timing: `nthreads` independent chains (seed+t), one per thread,
  * each running `sweeps` sweeps of the *_run form; returns wall seconds (sweep loop only,
  * set-up excluded), or a negative value on error.  sampler: 0 collapsed, 1 dp, 2 sb. ---- */

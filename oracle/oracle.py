@@ -201,7 +201,13 @@ def dp(X, nsamples, alpha, beta, gamma, a, b, burnin, maxK, seed, batch=1, liter
     return {"alpha": al, "z": z, "theta": th}
 
 
-def stickbreaking(X, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed, literal=False):
+def full(X, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed, literal=False):
+    """gibbs_cpp (full_gibbs.cpp): the stick-breaking z-step with a Dirichlet pi draw."""
+    return stickbreaking(X, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed, literal=literal,
+                         _fn=("oracle_full_literal" if literal else "oracle_full_run"))
+
+
+def stickbreaking(X, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burnin, seed, literal=False, _fn=None):
     X = _x(X)
     N, P = X.shape
     S = nsamples - burnin
@@ -210,7 +216,7 @@ def stickbreaking(X, pi0, theta0, nsamples, maxK, alpha, beta, gamma, a, b, burn
     assert pi0.shape == (maxK,) and theta0.shape == (maxK, P)
     z, th, al = _outs(S, N, maxK, P)
     pi = np.zeros((S, maxK), order="F")
-    fn = lib().oracle_sb_literal if literal else lib().oracle_sb_run
+    fn = getattr(lib(), _fn) if _fn else (lib().oracle_sb_literal if literal else lib().oracle_sb_run)
     rc = fn(_vp(X), C.c_int64(N), C.c_int(P), _vp(pi0), _vp(theta0), C.c_int(nsamples), C.c_int(maxK),
             C.c_double(alpha), C.c_double(beta), C.c_double(gamma), C.c_double(a), C.c_double(b),
             C.c_int(burnin), C.c_uint64(seed), _vp(pi), _vp(z), _vp(th), _vp(al))

@@ -139,6 +139,26 @@ def test_sb_synthetic_shapes(oracle, N, P, maxK):
     assert np.array_equal(got["pi"][0], pi0) and np.array_equal(got["theta"][:, :, 0], th0)
 
 
+# ---------------------------------------------------------------- full (uncollapsed) sampler, row f1
+@pytest.mark.parametrize("name,K", [("K2_N100_P5", 2), ("K3_N1000_P5", 3)])
+def test_full_bundled(oracle, name, K):
+    X = load_dataset(name)
+    pi0, th0 = _sb_init(K, 5, 5)
+    got = bm.gibbs_full(X, 80, K, seed=23, initial_pi=pi0, initial_theta=th0)
+    want = oracle.full(X, pi0, th0, 80, K, 0.0, 0.5, 0.5, 1, 1, 8, seed=23)
+    assert got["pi"].shape == (72, K)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+
+
+@pytest.mark.parametrize("N,P,K,alpha", [(5000, 50, 20, 0.0), (2222, 77, 9, 3.0)])
+def test_full_synthetic_shapes(oracle, N, P, K, alpha):
+    X, _, _, _ = synth(N, P, 5, 23)
+    pi0, th0 = _sb_init(K, P, 6)
+    got = bm.gibbs_full(X, 7, K, alpha=alpha, burnin=0, seed=2, initial_pi=pi0, initial_theta=th0)
+    want = oracle.full(X, pi0, th0, 7, K, alpha, 0.5, 0.5, 1, 1, 0, seed=2)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+
+
 # ---------------------------------------------------------------- resident chains and limits
 def test_resident_chain_matches_run_and_counts_are_consistent(oracle):
     X, _, _, _ = synth(20000, 24, 4, 18)
@@ -158,6 +178,33 @@ def test_resident_chain_matches_run_and_counts_are_consistent(oracle):
     assert np.array_equal(Nk, np.bincount(z - 1, minlength=4))
     for k in range(4):
         assert np.array_equal(S[k], X[z == k + 1].sum(axis=0))
+
+
+@pytest.mark.parametrize("N,P,K,batch", [(1, 3, 2, 1), (63, 1, 2, 63), (65, 16, 3, 7), (129, 17, 4, 129),
+                                         (1000, 128, 2, 999)])
+def test_collapsed_ragged_and_tiny(oracle, N, P, K, batch):
+    # fewer observations than a wave, stages that end mid-word, batches that end mid-wave
+    rng = np.random.default_rng(N)
+    X = np.asfortranarray(rng.integers(0, 2, (N, P)).astype(np.int32))
+    z0 = _z0(N, K, 1)
+    got = bm.gibbs_collapsed(X, 6, K, burnin=0, seed=7, batch=batch, initial_K=z0)
+    want = oracle.collapsed(X, z0, 6, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=7, batch=batch)
+    _same(got, want, ["z", "theta", "alpha"])
+
+
+def test_all_zero_and_all_one_columns(oracle):
+    # log(beta + 0) and log(gamma + 0) sides of the tables
+    X = np.zeros((500, 9), dtype=np.int32)
+    X[:, 3] = 1
+    X[::3, 5] = 1
+    X = np.asfortranarray(X)
+    z0 = _z0(500, 3, 4)
+    got = bm.gibbs_collapsed(X, 8, 3, burnin=1, seed=1, batch=50, initial_K=z0)
+    want = oracle.collapsed(X, z0, 8, 3, 0.0, 0.5, 0.5, 1, 1, 1, seed=1, batch=50)
+    _same(got, want, ["z", "theta", "alpha"])
+    got = bm.gibbs_dp(X, 8, burnin=1, seed=1, batch=50, maxK=6)
+    want = oracle.dp(X, 8, 0.0, 0.5, 0.5, 1, 1, 1, 6, seed=1, batch=50)
+    _same(got, want, ["z", "theta", "alpha"])
 
 
 def test_unsupported_shapes_fail_loudly():

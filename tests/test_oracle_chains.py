@@ -77,6 +77,28 @@ def test_sb_literal_equals_table_form(oracle):
     np.testing.assert_allclose(a["pi"].sum(axis=1), 1.0, atol=1e-12)
 
 
+def test_full_literal_equals_table_form_and_recovers_proportions(oracle):
+    # gibbs_cpp (full_gibbs.cpp:32): stick-breaking's z-step with pi ~ Dirichlet(alpha/K + counts)
+    X = load_dataset("K2_N1000_P5")
+    rng = np.random.default_rng(4)
+    K = 2
+    pi0 = np.exp(rng.random(K)); pi0 /= pi0.sum()
+    th0 = rng.random((K, 5))
+    a = oracle.full(X, pi0, th0, 60, K, 0.0, 0.5, 0.5, 1, 1, 10, seed=17, literal=True)
+    b = oracle.full(X, pi0, th0, 60, K, 0.0, 0.5, 0.5, 1, 1, 10, seed=17)
+    assert a["pi"].shape == (50, K) and a["theta"].shape == (K, 5, 50) and a["z"].shape == (50, 1000)
+    assert np.array_equal(a["z"], b["z"])
+    np.testing.assert_array_equal(a["pi"], b["pi"])
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    np.testing.assert_array_equal(a["alpha"], b["alpha"])
+    np.testing.assert_allclose(a["pi"].sum(axis=1), 1.0, atol=1e-12)
+    r = oracle.full(X, pi0, th0, 600, K, 0.0, 0.5, 0.5, 1, 1, 200, seed=17)
+    np.testing.assert_allclose(proportions(r["z"], K), [0.7, 0.3], atol=0.03)
+    # the Dirichlet draw differs from stick-breaking: same inputs, different chain
+    c = oracle.stickbreaking(X, pi0, th0, 60, K, 0.0, 0.5, 0.5, 1, 1, 10, seed=17)
+    assert not np.array_equal(b["pi"], c["pi"])
+
+
 def test_batched_collapsed_is_deterministic_and_differs_from_batch1(oracle):
     X, _, _, _ = synth(2000, 12, 3, 18)
     z0 = _z0(2000, 3, 2)
