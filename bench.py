@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5", "ns"])
     ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--k", type=int, default=0, help="override K (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
@@ -66,6 +67,9 @@ def main():
     sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
     if args.n:
         N = args.n
+    if args.k:
+        K = args.k
+        K_true = min(K_true, K)
 
     # data: generated in HBM on rank 0, broadcast once over RCCL/xGMI
     if rank == 0:

@@ -170,6 +170,34 @@ BMM_HD double exp_(double x) {
     return is_nan ? x : (over ? pos_inf() : (under ? 0.0 : y));
 }
 
+// exp_ restricted to x <= 0 (the sampler's max-shifted scores): bit-identical to exp_ there,
+// without the overflow and top-of-range handling.  A NaN argument (all scores -inf) gives an
+// unspecified value that the caller discards.
+BMM_HD double exp_nonpos(double x) {
+    const bool under = !(x >= -708.0);  // also catches NaN
+    const double xs = under ? 0.0 : x;
+    const double kd = floor_(fma_(xs, 1.44269504088896338700e+00, 0.5));
+    double r = fma_(-kd, 6.93147180369123816490e-01, xs);
+    r = fma_(-kd, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;
+    p = fma_(p, r, 2.0876756987868098979e-09);
+    p = fma_(p, r, 2.5052108385441718775e-08);
+    p = fma_(p, r, 2.7557319223985890653e-07);
+    p = fma_(p, r, 2.7557319223985892511e-06);
+    p = fma_(p, r, 2.4801587301587301566e-05);
+    p = fma_(p, r, 1.9841269841269841253e-04);
+    p = fma_(p, r, 1.3888888888888889419e-03);
+    p = fma_(p, r, 8.3333333333333332177e-03);
+    p = fma_(p, r, 4.1666666666666664354e-02);
+    p = fma_(p, r, 1.6666666666666665741e-01);
+    p = fma_(p, r, 0.5);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    const int k = (int)kd;  // in [-1021, 0]
+    const double y = p * dfrom((uint64_t)(k + 1023) << 52);
+    return under ? 0.0 : y;
+}
+
 // ---------------------------------------------------------------- variates
 // Standard normal by the Marsaglia polar method (log and sqrt only).
 BMM_HD double rnorm_(Stream& st) {

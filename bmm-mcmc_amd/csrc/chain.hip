@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -72,6 +74,18 @@ resample_fn resample_kernel_m(int kt) {
     }
     return nullptr;
 }
+// experiment hook (BMM_DEBUG_THREADS=768|512): the KT <= 20 kernels at a smaller workgroup
+template <int NT>
+resample_fn resample_kernel_dbg(int kt) {
+    switch (kt) {
+        case 4: return k_resample<4, NT, 1>;
+        case 8: return k_resample<8, NT, 1>;
+        case 12: return k_resample<12, NT, 1>;
+        case 16: return k_resample<16, NT, 1>;
+        case 20: return k_resample<20, NT, 1>;
+    }
+    return nullptr;
+}
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
 resample_fn resample_kernel(int kt, int minus) {
     return minus == 0 ? resample_kernel_m<0>(kt) : (minus == 1 ? resample_kernel_m<1>(kt) : resample_kernel_m<2>(kt));
@@ -116,6 +130,26 @@ namespace {
 // within seed noise of the sequential scan up to about N/8 on the hardest bundled data set
 // (no measurable shift at any batch on well-separated data); the DP sampler opens spurious
 // clusters above about N/16, because every "new" draw of a batch shares one label.
+// every cell of X must be 0 or 1: one streaming pass when the matrix is handed over
+int validate_binary(bmm_chain* c) {
+    int* dflag = nullptr;
+    HIP_TRY(hipMalloc(&dflag, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), c->stream));
+    const int64_t n = c->p.N * c->p.P;
+    const bool al16 = (reinterpret_cast<uintptr_t>(c->dX) & 15) == 0;
+    const int64_t n16 = al16 ? n / 4 : 0;
+    hipLaunchKernelGGL(k_validate_binary, dim3(2048), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint4*>(c->dX), n16, reinterpret_cast<const uint32_t*>(c->dX), n, dflag);
+    int flag = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dflag);
+    if (e != hipSuccess) return set_err(BMM_E_HIP, "validating X failed: %s", hipGetErrorString(e));
+    if (flag) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
+    return BMM_OK;
+}
+
 int64_t default_batch(int sampler, int64_t N) {
     if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
     int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
@@ -336,6 +370,13 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         return set_err(BMM_E_UNSUPPORTED, "K = %d, P = %d need %zu bytes of LDS tables; the CU has %zu", K, P, need, lds_max);
     }
     c->fn = resample_kernel(p.KT, explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2));
+    if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
+        const int nt = atoi(dbg);
+        resample_fn f = nullptr;
+        if (!explicit_params(p.mode) && c->minus_in_lds)
+            f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
+        if (f) { c->fn = f; c->NT = nt; }
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -391,6 +432,8 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
     HIP_TRY(hipMemcpyAsync(c->dX_owned, X, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dX = c->dX_owned;
+    int rc = validate_binary(c);
+    if (rc) return rc;
     c->have_data = true;
     return BMM_OK;
 }
@@ -405,6 +448,9 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
     }
     if (at.device != c->device) return set_err(BMM_E_ARG, "dX lives on device %d, chain on %d", at.device, c->device);
     c->dX = static_cast<const int32_t*>(dX);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = validate_binary(c);
+    if (rc) return rc;
     c->have_data = true;
     return BMM_OK;
 }

@@ -351,7 +351,7 @@ __device__ __forceinline__ uint32_t pack_stage(int P, int h, const uint32_t (&st
     const int nb = P - h * kStage < kStage ? P - h * kStage : kStage;
     uint32_t v = 0;
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) v |= (st[u] & 1u) << u;
+    for (int u = 0; u < kStage; ++u) v |= st[u] << u;  // X is validated to be 0/1 when it is set
     return v & ((1u << nb) - 1u);
 }
 // bits of stage h live in word h/2 at bit 16*(h%2)
@@ -405,6 +405,21 @@ __device__ __forceinline__ void flush_hist(const int32_t* hist, int K, int P, in
             else atomicAdd(&dNk[i - K * P], v);
         }
     }
+}
+
+// One pass over X when it is handed over: every cell must be 0 or 1 (the packing above
+// shifts the loaded words without masking).  flag[0] is set when one is not.
+__global__ __launch_bounds__(256) void k_validate_binary(const uint4* __restrict__ X4, int64_t n16,
+                                                         const uint32_t* __restrict__ X, int64_t n,
+                                                         int* __restrict__ flag) {
+    uint32_t bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = X4[i];
+        bad |= (v.x | v.y | v.z | v.w) & ~1u;
+    }
+    for (int64_t i = n16 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        bad |= X[i] & ~1u;
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // Statistics of a given allocation (the collapsed sampler's initial labels,
@@ -461,7 +476,7 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
 template <int KT, int NT, int MINUS>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
-    constexpr int CH = KT <= 12 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
+    constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
     static_assert(KT % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool has_minus = MINUS != 0;
@@ -591,7 +606,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double tot = 0.0;
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const double w = exp_(acc[k] - m);
+                const double w = exp_nonpos(acc[k] - m);
                 acc[k] = w;
                 tot = tot + w;
                 if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries
@@ -599,14 +614,19 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
             const double t = u * tot;
             double cdf = 0.0;
-            int cnt = 0, last = -1;
+            int cnt = 0;
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 cdf = cdf + acc[k];
                 cnt += t >= cdf ? 1 : 0;
-                last = acc[k] > 0.0 ? k : last;
             }
-            int zn = cnt < KT ? cnt : last;
+            int zn = cnt;
+            if (__any(cnt >= KT)) {  // u * tot rounded up to tot: the last category with weight
+                int last = -1;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) last = acc[k] > 0.0 ? k : last;
+                zn = cnt < KT ? cnt : last;
+            }
             if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
             if (p.mode == MODE_DP && zn == K) {
                 const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;

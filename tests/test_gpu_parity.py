@@ -207,6 +207,20 @@ def test_all_zero_and_all_one_columns(oracle):
     _same(got, want, ["z", "theta", "alpha"])
 
 
+def test_non_binary_data_is_rejected_by_the_c_abi():
+    import ctypes as C
+    from bmm_mcmc_amd import _capi
+    X = np.asfortranarray(np.random.default_rng(0).integers(0, 2, (300, 7)).astype(np.int32))
+    X[123, 4] = 2
+    z0 = np.ones(300, dtype=np.int32)
+    z = np.zeros((1, 300), dtype=np.int32, order="F"); th = np.zeros((2, 7, 1), order="F"); al = np.zeros((1, 1))
+    rc = _capi.lib().bmm_collapsed_run(_capi.vp(X), C.c_int64(300), C.c_int(7), _capi.vp(z0), C.c_int(3), C.c_int(2),
+                                       C.c_double(1.0), C.c_double(0.5), C.c_double(0.5), C.c_double(1), C.c_double(1),
+                                       C.c_int(2), C.c_int64(0), C.c_uint64(1), C.c_int(0), _capi.vp(z), _capi.vp(th),
+                                       _capi.vp(al))
+    assert rc == 1 and b"binary" in _capi.lib().bmm_last_error()
+
+
 def test_unsupported_shapes_fail_loudly():
     X = np.zeros((50, 200), dtype=np.int32)
     with pytest.raises(bm.BmmError, match="exceeds"):
