@@ -174,8 +174,8 @@ BMM_HD double exp_(double x) {
 // without the overflow and top-of-range handling.  A NaN argument (all scores -inf) gives an
 // unspecified value that the caller discards.
 BMM_HD double exp_nonpos(double x) {
-    const bool under = !(x >= -708.0);  // also catches NaN
-    const double xs = under ? 0.0 : x;
+    const bool ok = x >= -708.0;                     // false for NaN too
+    const double xs = __builtin_fmax(x, -708.0);     // NaN -> -708
     const double kd = floor_(fma_(xs, 1.44269504088896338700e+00, 0.5));
     double r = fma_(-kd, 6.93147180369123816490e-01, xs);
     r = fma_(-kd, 1.90821492927058770002e-10, r);
@@ -194,8 +194,9 @@ BMM_HD double exp_nonpos(double x) {
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
     const int k = (int)kd;  // in [-1021, 0]
-    const double y = p * dfrom((uint64_t)(k + 1023) << 52);
-    return under ? 0.0 : y;
+    // the scale 2^k is built in its high word; an underflowing argument gets scale 0
+    const uint32_t hi = ok ? (uint32_t)(k + 1023) << 20 : 0u;
+    return p * dfrom((uint64_t)hi << 32);
 }
 
 // ---------------------------------------------------------------- variates

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 double sc = Cp[k] + acc[k];
                 if (has_minus && k == zo) sc = cm_own + acc_own;
                 acc[k] = sc;
-                m = sc > m ? sc : m;
+                m = __builtin_fmax(m, sc);  // v_max_f64; scores are never NaN
             }
             double tot = 0.0;
 #pragma unroll
