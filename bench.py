@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
     ap.add_argument("--k", type=int, default=0, help="override K (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / north-star side measurements")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     args = ap.parse_args()
@@ -64,54 +65,56 @@ def main():
     dev = torch.device("cuda", local)
     multi.init("nccl", device=dev)
 
-    sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
-    if args.n:
-        N = args.n
-    if args.k:
-        K = args.k
-        K_true = min(K_true, K)
-
-    # data: generated in HBM on rank 0, broadcast once over RCCL/xGMI
-    if rank == 0:
-        X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
-    else:
-        X = torch.empty((P, N), dtype=torch.int32, device=dev)
-    multi.broadcast_data(X, src=0)
-    torch.cuda.synchronize()
-
-    seed = multi.chain_seed(1000, rank)  # chain seeds 1000 + c
-    ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
-                  batch=args.batch if args.batch > 0 else None, seed=seed, device=local)
-    batch = ch.batch  # the library default unless --batch was given
-    ch.set_data_device(X.data_ptr(), keepalive=X)
-    rng = np.random.default_rng(seed)
-    if sampler == "collapsed":
-        ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
-    elif sampler == "stickbreaking":
-        pi0 = np.exp(rng.random(K))
-        ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ch.sweeps(args.burn)
-    ch.sweeps(args.warmup)
-    ch.sync()
-    ch.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    ch.sweeps(args.steps)
-    ch.sync()
-    barrier()
-    t1 = time.perf_counter()
-    kern_ms, kern_n = ch.profile_read()
-    ch.profile(False)
-    shape = ch.kernel_shape()
+    def measure(workload, steps, warmup, burn, batch_arg, n_override=0, k_override=0):
+        """One chain per rank on `workload`; returns timing of `steps` sweeps (max over ranks)."""
+        sampler, K, K_true, N, P, dseed = synth.WORKLOADS[workload]
+        if n_override:
+            N = n_override
+        if k_override:
+            K = k_override
+            K_true = min(K_true, K)
+        # data: generated in HBM on rank 0, broadcast once over RCCL/xGMI
+        if rank == 0:
+            X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
+        else:
+            X = torch.empty((P, N), dtype=torch.int32, device=dev)
+        multi.broadcast_data(X, src=0)
+        torch.cuda.synchronize()
+        seed = multi.chain_seed(1000, rank)  # chain seeds 1000 + c (SURVEY.md section 8d)
+        ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
+                      batch=batch_arg if batch_arg > 0 else None, seed=seed, device=local)
+        ch.set_data_device(X.data_ptr(), keepalive=X)
+        rng = np.random.default_rng(seed)
+        if sampler == "collapsed":
+            ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+        elif sampler in ("stickbreaking", "full"):
+            pi0 = np.exp(rng.random(K))
+            ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+        ch.sweeps(burn)
+        ch.sweeps(warmup)
+        ch.sync()
+        ch.profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        ch.sweeps(steps)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        kern_ms, kern_n = ch.profile_read()
+        ch.profile(False)
+        m = {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
+             "dt": multi.max_over_ranks(t1 - t0), "kern_ms": multi.max_over_ranks(kern_ms), "kern_n": kern_n,
+             "X": X, "chain": ch}
+        return m
 
-    dt = multi.max_over_ranks(t1 - t0)
-    kern_ms = multi.max_over_ranks(kern_ms)
+    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k)
+    sampler, K, N, P, batch, shape = m["sampler"], m["K"], m["N"], m["P"], m["batch"], m["shape"]
+    dt, kern_ms, kern_n, X, ch = m["dt"], m["kern_ms"], m["kern_n"], m["X"], m["chain"]
 
     result = None
     if rank == 0:
@@ -165,8 +168,25 @@ def main():
                           "allocations/s / N" % (threads, cpu_sweeps, rows),
                 "allocations_per_s": alloc_s, "seconds": secs}
             result["config"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
     ch.close()
+    del X, m
+    torch.cuda.empty_cache()
+    # the other BASELINE points, measured in the same run (single GPU only): configs[1] and the
+    # north-star shape.  Reported beside the headline, never instead of it.
+    if world == 1 and not args.no_extra and args.workload == "c5" and not (args.n or args.k):
+        extra = {}
+        for w, steps in (("c2", 200), ("ns", 50)):
+            e = measure(w, steps, 5, args.burn, 0)
+            bps = e["N"] * (4 * e["P"] + 8)
+            extra[w] = {"workload": "gibbs_%s K=%d N=%d P=%d" % (e["sampler"], e["K"], e["N"], e["P"]),
+                        "sweeps_per_s": steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / steps,
+                        "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / steps,
+                        "algorithmic_GBps": bps * steps / (e["kern_ms"] * 1e-3) / 1e9,
+                        "note": "working set %.0f MB: cache-resident, not an HBM measurement" % (bps / 1e6)}
+            e["chain"].close()
+        result["other_workloads"] = extra
+    if rank == 0:
+        print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
     return result

@@ -243,6 +243,12 @@ class Chain:
     def sweeps(self, n):
         _capi.check(_capi.lib().bmm_chain_sweeps(self._h, _C.c_int(n)))
 
+    def sweeps_counts(self, n):
+        """n more sweeps; returns the (n, K) cluster sizes after each, computed on the device."""
+        out = _np.zeros((n, self.K), dtype=_np.int32)
+        _capi.check(_capi.lib().bmm_chain_sweeps_counts(self._h, _C.c_int(n), _capi.vp(out)))
+        return out
+
     def sync(self):
         _capi.check(_capi.lib().bmm_chain_sync(self._h))
 

@@ -116,6 +116,8 @@ struct bmm_chain {
     int32_t* dTrace = nullptr;  // [S][N], 0-based
     double *dThetaTrace = nullptr, *dAlphaTrace = nullptr, *dPiTrace = nullptr;
 
+    int32_t* dNkTrace = nullptr;  // [n][K] cluster sizes per sweep of the current sweeps_counts call
+    int nk_trace_base = 0;        // sweep index of its row 0
     unsigned long long* dDiag = nullptr;
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -237,12 +239,13 @@ int enqueue_sweep(bmm_chain* c, int j) {
     const int s = j - c->burnin;
     double* th_tr = rec ? c->dThetaTrace + (size_t)s * p.K * p.P : nullptr;
     double* al_tr = rec ? c->dAlphaTrace + s : nullptr;
+    int32_t* nk_tr = c->dNkTrace ? c->dNkTrace + (size_t)(j - c->nk_trace_base) * p.K : nullptr;
     if (explicit_params(p.mode)) {
         int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
-                           al_tr);
+                           al_tr, nk_tr);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
                            c->dPi, c->dTheta, 1, (uint32_t)j, th_tr, c->dTab);
@@ -264,7 +267,7 @@ int enqueue_sweep(bmm_chain* c, int j) {
         lo = hi;
     }
     hipLaunchKernelGGL(k_count_sweep_end, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
-                       c->dDS, c->dAlpha, (uint32_t)j, th_tr, al_tr);
+                       c->dDS, c->dAlpha, (uint32_t)j, th_tr, al_tr, nk_tr);
     HIP_TRY(hipGetLastError());
     return BMM_OK;
 }
@@ -497,6 +500,27 @@ int bmm_chain_sweeps(bmm_chain* c, int n) {
         c->sweep++;
     }
     return BMM_OK;
+}
+
+int bmm_chain_sweeps_counts(bmm_chain* c, int n, int32_t* nk_out) {
+    if (!c || !nk_out) return set_err(BMM_E_ARG, "null argument");
+    if (n < 0) return set_err(BMM_E_ARG, "n must be >= 0");
+    if (n == 0) return BMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * c->p.K * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&c->dNkTrace, bytes));
+    c->nk_trace_base = c->sweep + 1;
+    int rc = bmm_chain_sweeps(c, n);
+    if (rc == BMM_OK) {
+        hipError_t e = hipMemcpyAsync(nk_out, c->dNkTrace, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = set_err(BMM_E_HIP, "copying the count trace failed: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(c->dNkTrace);
+    c->dNkTrace = nullptr;
+    return rc;
 }
 
 int bmm_chain_sync(bmm_chain* c) {

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
                                                    int32_t* __restrict__ dS, double* __restrict__ alpha_ptr,
                                                    double* __restrict__ pi, uint32_t sweep,
                                                    double* __restrict__ pi_trace, int pi_stride,
-                                                   double* __restrict__ alpha_trace) {
+                                                   double* __restrict__ alpha_trace,
+                                                   int32_t* __restrict__ nk_trace) {
     __shared__ int32_t ck[kMaxCats];
     __shared__ double v[kMaxCats];
     const int K = p.K, P = p.P;
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + dNk[k];
         Nk[k] = n; dNk[k] = 0; ck[k] = n;
+        if (nk_trace) nk_trace[k] = n;
     }
     __syncthreads();
     const double alpha_prev = *alpha_ptr;
@@ -258,12 +260,14 @@ __global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t*
                                                          int32_t* __restrict__ dS,
                                                          double* __restrict__ alpha_ptr, uint32_t sweep,
                                                          double* __restrict__ theta_trace,
-                                                         double* __restrict__ alpha_trace) {
+                                                         double* __restrict__ alpha_trace,
+                                                         int32_t* __restrict__ nk_trace) {
     __shared__ int32_t nk[kMaxCats];
     const int K = p.K, P = p.P;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + dNk[k];
         Nk[k] = n; dNk[k] = 0; nk[k] = n;
+        if (nk_trace) nk_trace[k] = n;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {

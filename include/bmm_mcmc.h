@@ -101,6 +101,10 @@ int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* t
 /* enqueue n more sweeps on the chain's stream (returns without waiting) */
 int bmm_chain_sweeps(bmm_chain* c, int n);
 int bmm_chain_sync(bmm_chain* c);
+/* n more sweeps, returning the cluster sizes after each one (nk_out is n x K, row-major: sweep,
+ * label) -- the per-sweep summary plot_gibbs derives from z (R/utils.R:146-173) without moving
+ * the 4*N-byte label row off the device each sweep.  Waits. */
+int bmm_chain_sweeps_counts(bmm_chain* c, int n, int32_t* nk_out);
 int bmm_chain_sweep_index(const bmm_chain* c); /* sweeps done so far */
 /* current state, copied to host: labels 1-based (NA where unassigned) */
 int bmm_chain_get_labels(bmm_chain* c, int32_t* z1);

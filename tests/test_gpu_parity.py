@@ -221,6 +221,28 @@ def test_non_binary_data_is_rejected_by_the_c_abi():
     assert rc == 1 and b"binary" in _capi.lib().bmm_last_error()
 
 
+def test_device_side_count_summaries_match_the_label_trace(oracle):
+    # row f3: per-sweep cluster sizes without the S x N label matrix
+    X, _, _, _ = synth(9000, 30, 5, 18)
+    z0 = _z0(9000, 6, 3)
+    with bm.Chain("collapsed", 9000, 30, 6, batch=1000, seed=8) as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        nk = ch.sweeps_counts(5)
+    want = oracle.collapsed(X, z0, 8, 6, 0.0, 0.5, 0.5, 1, 1, 3, seed=8, batch=1000)
+    for s in range(5):
+        assert np.array_equal(nk[s], np.bincount(want["z"][s] - 1, minlength=6))
+    pi0, th0 = _sb_init(7, 30, 2)
+    with bm.Chain("stickbreaking", 9000, 30, 7, seed=8) as ch:
+        ch.set_data(X)
+        ch.set_initial_params(pi0, th0)
+        nk = ch.sweeps_counts(4)
+    want = oracle.stickbreaking(X, pi0, th0, 5, 7, 0.0, 0.5, 0.5, 1, 1, 1, seed=8)
+    for s in range(4):
+        assert np.array_equal(nk[s], np.bincount(want["z"][s] - 1, minlength=7))
+
+
 def test_unsupported_shapes_fail_loudly():
     X = np.zeros((50, 200), dtype=np.int32)
     with pytest.raises(bm.BmmError, match="exceeds"):
