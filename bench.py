@@ -66,7 +66,7 @@ def main():
     multi.init("nccl", device=dev)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +187,7 @@ def main():
         result["other_workloads"] = extra
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return result
 

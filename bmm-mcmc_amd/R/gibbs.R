@@ -1,62 +1,72 @@
-# R wrappers over the MI355X allocation path: the signatures of the reference's
-# R/utils.R:23-47,95-107 with three optional trailing arguments (seed, batch, and for
-# the stick-breaking sampler seed only).  Old calls stay valid; the returned lists have
-# the reference's names, order, storage modes and dims.  When `seed` is NULL one integer
-# is drawn from R's own RNG, so set.seed() still fixes the chain.
+# R front end of the MI355X allocation path.
+#
+# Same call signatures as the reference's exported samplers (R/utils.R:23-24, 37-39, 64-66,
+# 95-96 of stulacy/bmm-mcmc) with optional trailing `seed` / `batch`, so existing calls keep
+# working; the lists that come back carry the reference's element names, order, storage
+# modes and dims.  Everything below the `.Call` is bmm-mcmc_amd/r-shim/bmmmcmc_shim.c.
 
-.bmm_seed <- function(seed) if (is.null(seed)) sample.int(.Machine$integer.max, 1) else seed
+.bmm <- new.env()
+
+# burn-in default (a tenth of the run) and the burnrelabel clamp the reference applies
+.bmm$schedule <- function(nsamples, burnin, burnrelabel, clamp = TRUE) {
+    burnin <- if (is.null(burnin)) round(nsamples / 10) else burnin
+    if (clamp && burnrelabel > burnin) burnrelabel <- round(burnin / 10)
+    list(burnin = burnin, burnrelabel = burnrelabel)
+}
+
+# NULL concentration means "sample it", which the native side encodes as 0
+.bmm$conc <- function(alpha) if (is.null(alpha)) 0 else alpha
+
+# one integer from R's own stream when no seed is given: set.seed() still fixes the chain
+.bmm$key <- function(seed) as.numeric(if (is.null(seed)) sample.int(.Machine$integer.max, 1) else seed)
+
+.bmm$ints <- function(data) {
+    m <- as.matrix(data)
+    storage.mode(m) <- "integer"
+    m
+}
+
+# starting weights and success probabilities of the samplers that carry them explicitly
+.bmm$start <- function(k, p) {
+    w <- exp(stats::runif(k))
+    list(pi = w / sum(w), theta = matrix(stats::runif(k * p), nrow = k, ncol = p))
+}
+
+gibbs_collapsed <- function(data, nsamples, K, alpha=NULL, beta=0.5, gamma=0.5, a=1, b=1,
+                            burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE,
+                            seed=NULL, batch=0) {
+    s <- .bmm$schedule(nsamples, burnin, burnrelabel)
+    x <- .bmm$ints(data)
+    z0 <- sample.int(K, nrow(x), replace = TRUE)
+    .Call("_bmmmcmc_collapsed_gibbs_cpp", PACKAGE = "bmmmcmc", x, z0, nsamples, K, .bmm$conc(alpha),
+          beta, gamma, a, b, s$burnin, relabel, s$burnrelabel, debug, .bmm$key(seed), as.numeric(batch))
+}
 
 gibbs_dp <- function(data, nsamples, alpha=NULL, a=1, b=1, beta=0.5, gamma=0.5,
                      burnin=NULL, relabel=FALSE, burnrelabel=50, maxK=30, debug=FALSE,
                      seed=NULL, batch=0) {
-    if (is.null(burnin)) burnin <- round(0.1 * nsamples)
-    if (burnrelabel > burnin) burnrelabel <- round(0.1 * burnin)
-    if (is.null(alpha)) alpha <- 0
-    storage.mode(data) <- "integer"
-    .Call('_bmmmcmc_collapsed_gibbs_dp_cpp', PACKAGE = 'bmmmcmc', data, nsamples, alpha, beta, gamma,
-          a, b, burnin, relabel, burnrelabel, maxK, debug, as.numeric(.bmm_seed(seed)), as.numeric(batch))
+    s <- .bmm$schedule(nsamples, burnin, burnrelabel)
+    .Call("_bmmmcmc_collapsed_gibbs_dp_cpp", PACKAGE = "bmmmcmc", .bmm$ints(data), nsamples,
+          .bmm$conc(alpha), beta, gamma, a, b, s$burnin, relabel, s$burnrelabel, maxK, debug,
+          .bmm$key(seed), as.numeric(batch))
 }
 
-gibbs_collapsed <- function(data, nsamples, K, alpha=NULL, beta=0.5, gamma=0.5,
-                            a=1, b=1,
-                            burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE,
-                            seed=NULL, batch=0) {
-    if (is.null(burnin)) burnin <- round(0.1 * nsamples)
-    if (burnrelabel > burnin) burnrelabel <- round(0.1 * burnin)
-    initial_K <- sample(1:K, nrow(data), replace=T)
-    if (is.null(alpha)) alpha <- 0
-    storage.mode(data) <- "integer"
-    .Call('_bmmmcmc_collapsed_gibbs_cpp', PACKAGE = 'bmmmcmc', data, initial_K, nsamples, K, alpha,
-          beta, gamma, a, b, burnin, relabel, burnrelabel, debug, as.numeric(.bmm_seed(seed)),
-          as.numeric(batch))
+gibbs_full <- function(data, nsamples, K, alpha=NULL, beta=0.5, gamma=0.5, a=1, b=1,
+                       burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE, seed=NULL) {
+    s <- .bmm$schedule(nsamples, burnin, burnrelabel)
+    x <- .bmm$ints(data)
+    init <- .bmm$start(K, ncol(x))
+    .Call("_bmmmcmc_gibbs_cpp", PACKAGE = "bmmmcmc", x, init$pi, init$theta, nsamples, K,
+          .bmm$conc(alpha), beta, gamma, a, b, s$burnin, relabel, s$burnrelabel, debug, .bmm$key(seed))
 }
 
 gibbs_stickbreaking <- function(data, nsamples, maxK, alpha=NULL, beta=0.5, gamma=0.5, a=1, b=1,
                                 burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE, seed=NULL) {
-    if (is.null(burnin)) burnin <- round(0.1 * nsamples)
-    initial_pi <- stats::runif(maxK)
-    initial_pi <- exp(initial_pi)
-    initial_pi <- initial_pi / sum(initial_pi)
-    if (is.null(alpha)) alpha <- 0
-    initial_theta <- matrix(stats::runif(maxK*ncol(data)), ncol=ncol(data), nrow=maxK)
-    storage.mode(data) <- "integer"
-    .Call('_bmmmcmc_gibbs_stickbreaking_cpp', PACKAGE = 'bmmmcmc', data, initial_pi, initial_theta,
-          nsamples, maxK, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug,
-          as.numeric(.bmm_seed(seed)))
-}
-
-gibbs_full <- function(data, nsamples, K, alpha=NULL, beta=0.5, gamma=0.5,
-                       a=1, b=1,
-                       burnin=NULL, relabel=FALSE, burnrelabel=50, debug=FALSE, seed=NULL) {
-    if (is.null(burnin)) burnin <- round(0.1 * nsamples)
-    initial_pi <- stats::runif(K)
-    initial_pi <- exp(initial_pi)
-    initial_pi <- initial_pi / sum(initial_pi)
-    if (is.null(alpha)) alpha <- 0
-    if (burnrelabel > burnin) burnrelabel <- round(0.1 * burnin)
-    initial_theta <- matrix(stats::runif(K*ncol(data)), ncol=ncol(data), nrow=K)
-    storage.mode(data) <- "integer"
-    .Call('_bmmmcmc_gibbs_cpp', PACKAGE = 'bmmmcmc', data, initial_pi, initial_theta,
-          nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug,
-          as.numeric(.bmm_seed(seed)))
+    # the reference does not clamp burnrelabel in this wrapper (R/utils.R:97-101)
+    s <- .bmm$schedule(nsamples, burnin, burnrelabel, clamp = FALSE)
+    x <- .bmm$ints(data)
+    init <- .bmm$start(maxK, ncol(x))
+    .Call("_bmmmcmc_gibbs_stickbreaking_cpp", PACKAGE = "bmmmcmc", x, init$pi, init$theta, nsamples,
+          maxK, .bmm$conc(alpha), beta, gamma, a, b, s$burnin, relabel, s$burnrelabel, debug,
+          .bmm$key(seed))
 }

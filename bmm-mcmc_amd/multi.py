@@ -24,7 +24,8 @@ def init(backend=None, device=None):
     """Join the process group if launched with more than one rank.  Returns (world, rank, local)."""
     import torch.distributed as dist
     w, r, l = world()
-    if w > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
+    if (w > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
