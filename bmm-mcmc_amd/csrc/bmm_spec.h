@@ -137,67 +137,87 @@ BMM_HD double log_(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
-// exp(x): k = round(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r, scale by 2^k.
-// Results below 2^-1021 are flushed to 0 (x < -708); the sampler never needs them.
-BMM_HD double exp_(double x) {
+// exp(x) = 2^k * 2^(j/64) * e^r with 64k + j = round(x * 64/ln2), r = x - (64k+j) ln2/64
+// (two-part), |r| <= ln2/128: e^r - 1 by a degree-5 Taylor polynomial (truncation < 2^-54),
+// 2^(j/64) from a 64-entry table of correctly rounded doubles (tools/gen_exp_table.py).
+// Error < 1 ulp.  Results below 2^-1021 are flushed to 0 (x < -708); the sampler never needs them.
+#define BMM_EXP2_64_TABLE \
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0, \
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0, \
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0, \
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0, \
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0, \
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0, \
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0, \
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0, \
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0, \
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0, \
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0, \
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0, \
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0, \
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0, \
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0, \
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+static const double kExp2Host[64] = {BMM_EXP2_64_TABLE};
+#if defined(__HIPCC__)
+__constant__ double kExp2Dev[64] = {BMM_EXP2_64_TABLE};
+#endif
+BMM_HD const double* exp2_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kExp2Dev;
+#else
+    return kExp2Host;
+#endif
+}
+
+// core for an argument already known to be in [-708, 709.79]; Tab is any pointer-like to the table
+template <class Tab>
+BMM_HD double exp_core(double xs, Tab T, int& k_out) {
+    const double kd = floor_(fma_(xs, 9.23324826168936567e+01, 0.5));   // 64/ln2
+    double r = fma_(-kd, 1.08304246962491454e-02, xs);                   // ln2/64, high part
+    r = fma_(-kd, 3.62351064663484299e-19, r);                           // low part
+    const int ki = (int)kd;
+    const int j = ki & 63;
+    k_out = ki >> 6;
+    double c = fma_(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);  // 1/120, 1/24
+    c = fma_(r, c, 1.6666666666666665741e-01);                                  // 1/6
+    c = fma_(r, c, 0.5);
+    const double q = fma_(r * r, c, r);
+    const double t = T[j];
+    return fma_(t, q, t);
+}
+
+template <class Tab>
+BMM_HD double exp_tab(double x, Tab T) {
     // written select-style (no early returns) so that the device code is branch-free
     const bool is_nan = x != x;
     const bool over = x > 709.782712893384;
     const bool under = x < -708.0;
     const double xs = (is_nan || over || under) ? 0.0 : x;
-    const double kd = floor_(fma_(xs, 1.44269504088896338700e+00, 0.5));
-    double r = fma_(-kd, 6.93147180369123816490e-01, xs);
-    r = fma_(-kd, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;            // 1/13!
-    p = fma_(p, r, 2.0876756987868098979e-09);       // 1/12!
-    p = fma_(p, r, 2.5052108385441718775e-08);       // 1/11!
-    p = fma_(p, r, 2.7557319223985890653e-07);       // 1/10!
-    p = fma_(p, r, 2.7557319223985892511e-06);       // 1/9!
-    p = fma_(p, r, 2.4801587301587301566e-05);       // 1/8!
-    p = fma_(p, r, 1.9841269841269841253e-04);       // 1/7!
-    p = fma_(p, r, 1.3888888888888889419e-03);       // 1/6!
-    p = fma_(p, r, 8.3333333333333332177e-03);       // 1/5!
-    p = fma_(p, r, 4.1666666666666664354e-02);       // 1/4!
-    p = fma_(p, r, 1.6666666666666665741e-01);       // 1/3!
-    p = fma_(p, r, 0.5);
-    p = fma_(p, r, 1.0);
-    p = fma_(p, r, 1.0);
-    int k = (int)kd;
+    int k;
+    double p = exp_core(xs, T, k);
     const bool top = k > 1023;
     p = top ? p * 2.0 : p;
     k = top ? k - 1 : k;
     const double y = p * dfrom((uint64_t)(k + 1023) << 52);
     return is_nan ? x : (over ? pos_inf() : (under ? 0.0 : y));
 }
+BMM_HD double exp_(double x) { return exp_tab(x, exp2_table()); }
 
 // exp_ restricted to x <= 0 (the sampler's max-shifted scores): bit-identical to exp_ there,
 // without the overflow and top-of-range handling.  A NaN argument (all scores -inf) gives an
 // unspecified value that the caller discards.
-BMM_HD double exp_nonpos(double x) {
+template <class Tab>
+BMM_HD double exp_nonpos_tab(double x, Tab T) {
     const bool ok = x >= -708.0;                     // false for NaN too
     const double xs = __builtin_fmax(x, -708.0);     // NaN -> -708
-    const double kd = floor_(fma_(xs, 1.44269504088896338700e+00, 0.5));
-    double r = fma_(-kd, 6.93147180369123816490e-01, xs);
-    r = fma_(-kd, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;
-    p = fma_(p, r, 2.0876756987868098979e-09);
-    p = fma_(p, r, 2.5052108385441718775e-08);
-    p = fma_(p, r, 2.7557319223985890653e-07);
-    p = fma_(p, r, 2.7557319223985892511e-06);
-    p = fma_(p, r, 2.4801587301587301566e-05);
-    p = fma_(p, r, 1.9841269841269841253e-04);
-    p = fma_(p, r, 1.3888888888888889419e-03);
-    p = fma_(p, r, 8.3333333333333332177e-03);
-    p = fma_(p, r, 4.1666666666666664354e-02);
-    p = fma_(p, r, 1.6666666666666665741e-01);
-    p = fma_(p, r, 0.5);
-    p = fma_(p, r, 1.0);
-    p = fma_(p, r, 1.0);
-    const int k = (int)kd;  // in [-1021, 0]
+    int k;                                           // in [-1022, 0]
+    const double p = exp_core(xs, T, k);
     // the scale 2^k is built in its high word; an underflowing argument gets scale 0
     const uint32_t hi = ok ? (uint32_t)(k + 1023) << 20 : 0u;
     return p * dfrom((uint64_t)hi << 32);
 }
+BMM_HD double exp_nonpos(double x) { return exp_nonpos_tab(x, exp2_table()); }
 
 // ---------------------------------------------------------------- variates
 // Standard normal by the Marsaglia polar method (log and sqrt only).

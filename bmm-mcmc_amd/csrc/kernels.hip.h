@@ -40,6 +40,7 @@ __host__ __device__ inline bool explicit_params(int mode) { return mode == MODE_
 //   Cp  [KT]          prior / weight term per category
 //   Cm  [KT]          ... with the scored observation removed from its own cluster
 //   Nk  [KT] int32    (two per double slot, padded to an even number of doubles)
+//   E   [64]          2^(j/64), the table of the spec's exp_ (read per lane in the draw)
 //   Tm  [G][KT][16]   group tables with the observation's own contribution removed (not SB)
 // A workgroup copies the head (Tp..Nk) into LDS, and Tm too when both fit in 160 KiB;
 // otherwise Tm is gathered from global memory (L2-resident, 1/K of the lookups).
@@ -49,7 +50,8 @@ struct TableLayout {
     __host__ __device__ int cp() const { return G * KT * kGroupM; }
     __host__ __device__ int cm() const { return cp() + KT; }
     __host__ __device__ int nk() const { return cm() + KT; }
-    __host__ __device__ int tm() const { return nk() + (KT + 1) / 2 + (((KT + 1) / 2) & 1); }
+    __host__ __device__ int et() const { return nk() + (KT + 1) / 2 + (((KT + 1) / 2) & 1); }
+    __host__ __device__ int tm() const { return et() + 64; }
     __host__ __device__ int head() const { return tm(); }
     __host__ __device__ int doubles() const { return tm() + (has_minus ? G * KT * kGroupM : 0); }
 };
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(128) void k_count_tables(ChainParams p, int32_t* __
         tab[L.cm() + k] = cm;
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
     }
+    if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
 }
 
 // Stick-breaking: theta_kd ~ Beta(beta + V_kd, gamma + c_k - V_kd) (stickbreaking.cpp:217-229),
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(128) void k_sb_theta_tables(ChainParams p, const in
         tab[L.cm() + k] = neg_inf();
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
     }
+    if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
 }
 
 // Stick-breaking: fold deltas, v_k ~ Beta(1 + c_k, alpha + sum_{l>k} c_l), pi by stick
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const double* const Cp = lds + L.cp();
     const double* const Cm = lds + L.cm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(lds + L.nk());
+    const lds_f64* const ET = (const lds_f64*)(lds + L.et());
     int32_t* const hist = reinterpret_cast<int32_t*>(lds + lds_doubles);  // [K*P] then [K]
     const int P = p.P, G = p.G, K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -509,9 +514,24 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     if (has_tile) issue_stage(pos, p.N, P, 0, st);
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     {
+        // stage the table image: eight 16-byte loads in flight per lane (one L2 round trip per
+        // eight, not per one)
         const double2* src = reinterpret_cast<const double2*>(a.tab);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < lds_doubles / 2; i += NT) dst[i] = src[i];
+        const int n2 = lds_doubles / 2;
+        for (int i0 = tid; i0 < n2; i0 += NT * 8) {
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NT;
+                t[u] = src[i < n2 ? i : n2 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NT;
+                if (i < n2) dst[i] = t[u];
+            }
+        }
     }
     for (int i = tid; i < K * P + K; i += NT) hist[i] = 0;
     __syncthreads();
@@ -610,7 +630,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double tot = 0.0;
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const double w = exp_nonpos(acc[k] - m);
+                const double w = exp_nonpos_tab(acc[k] - m, ET);
                 acc[k] = w;
                 tot = tot + w;
                 if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries

@@ -80,23 +80,41 @@ double oracle_log(double x) {
            ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
-/* exp: k = round(x/ln2), two-part reduction, degree-13 Taylor, scale by 2^k;
- * x < -708 flushes to 0. */
+/* exp: 64k + j = round(x * 64/ln2), r = x - (64k+j) ln2/64 in two parts, e^r - 1 by a degree-5
+ * Taylor polynomial, times the tabulated 2^(j/64), times 2^k; x < -708 flushes to 0. */
+static const double o_exp2_64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
 double oracle_exp(double x) {
-    static const double c[14] = {
-        1.0, 1.0, 0.5, 1.6666666666666665741e-01, 4.1666666666666664354e-02,
-        8.3333333333333332177e-03, 1.3888888888888889419e-03, 1.9841269841269841253e-04,
-        2.4801587301587301566e-05, 2.7557319223985892511e-06, 2.7557319223985890653e-07,
-        2.5052108385441718775e-08, 2.0876756987868098979e-09, 1.6059043836821614599e-10};
     if (x != x) return x;
     if (x > 709.782712893384) return O_POS_INF;
     if (x < -708.0) return 0.0;
-    double kd = __builtin_floor(__builtin_fma(x, 1.44269504088896338700e+00, 0.5));
-    double r = __builtin_fma(-kd, 6.93147180369123816490e-01, x);
-    r = __builtin_fma(-kd, 1.90821492927058770002e-10, r);
-    double p = c[13];
-    for (int n = 12; n >= 0; --n) p = __builtin_fma(p, r, c[n]);
-    int k = (int)kd;
+    double kd = __builtin_floor(__builtin_fma(x, 0x1.71547652b82fep+6, 0.5));
+    double r = __builtin_fma(-kd, 0x1.62e42fefa39efp-7, x);
+    r = __builtin_fma(-kd, 0x1.abc9e3b39803fp-62, r);
+    int ki = (int)kd;
+    int j = ki & 63, k = ki >> 6;
+    double c = __builtin_fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);
+    c = __builtin_fma(r, c, 1.6666666666666665741e-01);
+    c = __builtin_fma(r, c, 0.5);
+    double q = __builtin_fma(r * r, c, r);
+    double t = o_exp2_64[j];
+    double p = __builtin_fma(t, q, t);
     if (k > 1023) { p *= 2.0; k -= 1; }
     return p * u2d((uint64_t)(k + 1023) << 52);
 }
