@@ -47,6 +47,10 @@ const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
 constexpr int kThreadsSmall = 1024;  // KT <= 12: 128 VGPRs
 constexpr int kThreadsMid = 768;     // KT 16, 20: 168 VGPRs
 constexpr int kThreadsLarge = 512;   // 256 VGPRs
+#ifndef BMM_STAGE_WIDE
+#define BMM_STAGE_WIDE 32
+#endif
+constexpr int kStageWide = BMM_STAGE_WIDE;  // features in flight per wave where registers allow
 
 int pick_kt(int cats) {
     for (int kt : kKT)
@@ -59,18 +63,18 @@ typedef void (*resample_fn)(ChainParams, ResampleArgs);
 template <int MINUS>
 resample_fn resample_kernel_m(int kt) {
     switch (kt) {
-        case 4: return k_resample<4, kThreadsSmall, MINUS>;
-        case 8: return k_resample<8, kThreadsSmall, MINUS>;
-        case 12: return k_resample<12, kThreadsSmall, MINUS>;
-        case 16: return k_resample<16, kThreadsMid, MINUS>;
-        case 20: return k_resample<20, kThreadsMid, MINUS>;
-        case 24: return k_resample<24, kThreadsLarge, MINUS>;
-        case 28: return k_resample<28, kThreadsLarge, MINUS>;
-        case 32: return k_resample<32, kThreadsLarge, MINUS>;
-        case 40: return k_resample<40, kThreadsLarge, MINUS>;
-        case 48: return k_resample<48, kThreadsLarge, MINUS>;
-        case 56: return k_resample<56, kThreadsLarge, MINUS>;
-        case 64: return k_resample<64, kThreadsLarge, MINUS>;
+        case 4: return k_resample<4, kThreadsSmall, MINUS, kStageWide>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS, kStageWide>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS, kStageWide>;
+        case 16: return k_resample<16, kThreadsMid, MINUS, kStageWide>;
+        case 20: return k_resample<20, kThreadsMid, MINUS, kStageWide>;
+        case 24: return k_resample<24, kThreadsLarge, MINUS, 16>;
+        case 28: return k_resample<28, kThreadsLarge, MINUS, 16>;
+        case 32: return k_resample<32, kThreadsLarge, MINUS, 16>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS, 16>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS, 16>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS, 16>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS, 16>;
     }
     return nullptr;
 }
@@ -78,11 +82,11 @@ resample_fn resample_kernel_m(int kt) {
 template <int NT>
 resample_fn resample_kernel_dbg(int kt) {
     switch (kt) {
-        case 4: return k_resample<4, NT, 1>;
-        case 8: return k_resample<8, NT, 1>;
-        case 12: return k_resample<12, NT, 1>;
-        case 16: return k_resample<16, NT, 1>;
-        case 20: return k_resample<20, NT, 1>;
+        case 4: return k_resample<4, NT, 1, kStageWide>;
+        case 8: return k_resample<8, NT, 1, kStageWide>;
+        case 12: return k_resample<12, NT, 1, kStageWide>;
+        case 16: return k_resample<16, NT, 1, kStageWide>;
+        case 20: return k_resample<20, NT, 1, kStageWide>;
     }
     return nullptr;
 }

@@ -340,32 +340,42 @@ __device__ __forceinline__ TilePos tile_pos(const ResampleArgs& a, int64_t tile,
 // buffer form: the descriptor (SGPRs) carries the wave-uniform column base and is advanced
 // by the column stride between loads; the lane offset is one shared VGPR.  No per-load
 // address registers: the kStage loads of one stage are in flight from kStage + 1 VGPRs.
-constexpr int kStage = 16;  // features per pipeline stage (= 4 lookup groups)
+// STG = features per pipeline stage (16 or 32 = 4 or 8 lookup groups); template parameter below
 
-__device__ __forceinline__ void issue_stage(const TilePos& t, int64_t N, int P, int h, uint32_t (&st)[kStage]) {
-    const int d0 = h * kStage;
+template <int STG>
+__device__ __forceinline__ void issue_stage(const TilePos& t, int64_t N, int P, int h, uint32_t (&st)[STG]) {
+    const int d0 = h * STG;
+    const int nb = P - d0 < STG ? P - d0 : STG;
     const int64_t stride = N * 4;
     const char* col = t.base + (int64_t)d0 * stride;
-    // a partial last stage re-reads feature P-1 (same cache lines); pack_stage masks it off
+    // a partial last stage loads whole groups of four only (the tail re-reads feature P-1: same
+    // cache lines; pack_stage masks it off)
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) {
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(col), 0, 0x7fffffff, 0x00020000);
-        st[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)t.voff, 0, 0);
-        col += d0 + u + 1 < P ? stride : 0;
+    for (int u0 = 0; u0 < STG; u0 += 4) {
+        if (u0 < nb) {
+#pragma unroll
+            for (int u = u0; u < u0 + 4; ++u) {
+                const __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(col), 0, 0x7fffffff, 0x00020000);
+                st[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)t.voff, 0, 0);
+                col += d0 + u + 1 < P ? stride : 0;
+            }
+        }
     }
 }
-__device__ __forceinline__ uint32_t pack_stage(int P, int h, const uint32_t (&st)[kStage]) {
-    const int nb = P - h * kStage < kStage ? P - h * kStage : kStage;
+template <int STG>
+__device__ __forceinline__ uint32_t pack_stage(int P, int h, const uint32_t (&st)[STG]) {
+    const int nb = P - h * STG < STG ? P - h * STG : STG;
     uint32_t v = 0;
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) v |= st[u] << u;  // X is validated to be 0/1 when it is set
-    return v & ((1u << nb) - 1u);
+    for (int u = 0; u < STG; ++u) v |= st[u] << u;  // X is validated to be 0/1 when it is set
+    return nb >= 32 ? v : (v & ((1u << nb) - 1u));
 }
-// bits of stage h live in word h/2 at bit 16*(h%2)
+// bits of stage h live in word h*STG/32 at bit (h*STG)%32
+template <int STG>
 __device__ __forceinline__ void put_stage(uint32_t v, int h, uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
-    const uint32_t sh = v << ((h & 1) * kStage);
-    const int w = h >> 1;
+    const uint32_t sh = STG == 32 ? v : v << ((h & 1) * 16);
+    const int w = STG == 32 ? h : h >> 1;
     b0 |= w == 0 ? sh : 0u;
     b1 |= w == 1 ? sh : 0u;
     b2 |= w == 2 ? sh : 0u;
@@ -443,14 +453,16 @@ __global__ __launch_bounds__(256) void k_count_labels(ChainParams p, const int32
     ResampleArgs a{};
     a.X = X; a.lo = 0; a.hi = p.N;
     const int64_t ntiles = (p.N + 255) / 256;
-    const int nstages = (P + kStage - 1) / kStage;
+    const int nstages = (P + 15) / 16;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const TilePos pos = tile_pos(a, tile, 256, tid, lane);
-        uint32_t st[kStage], b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        uint32_t st[16], b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) st[u] = 0;
 #pragma unroll 1
         for (int h = 0; h < nstages; ++h) {
-            issue_stage(pos, p.N, P, h, st);
-            put_stage(pack_stage(P, h, st), h, b0, b1, b2, b3);
+            issue_stage<16>(pos, p.N, P, h, st);
+            put_stage<16>(pack_stage<16>(P, h, st), h, b0, b1, b2, b3);
         }
         const int zl = z[pos.ic];
         count_movers(pos.valid && zl >= 0, -1, zl, b0, b1, b2, b3, hist, K, P, lane);
@@ -482,8 +494,9 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // MINUS says where the own-cluster ("minus self") tables are: 0 none (stick-breaking),
 // 1 in LDS, 2 in global memory.  It is a template parameter because a possible VMEM load in
 // the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
-template <int KT, int NT, int MINUS>
+template <int KT, int NT, int MINUS, int STG>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    constexpr int GPS = STG / kGroupW;  // lookup groups per stage
     constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
     static_assert(KT % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -502,16 +515,16 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const int P = p.P, G = p.G, K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t ntiles = (a.hi - a.lo + NT - 1) / NT;
-    const int nstages = (P + kStage - 1) / kStage;
+    const int nstages = (P + STG - 1) / STG;
 
     int64_t tile = blockIdx.x;
     const bool has_tile = tile < ntiles;
-    uint32_t st[kStage];
+    uint32_t st[STG];
 #pragma unroll
-    for (int u = 0; u < kStage; ++u) st[u] = 0;
+    for (int u = 0; u < STG; ++u) st[u] = 0;
     TilePos pos = tile_pos(a, has_tile ? tile : 0, NT, tid, lane);
     // first loads of the first tile go out before the tables are staged
-    if (has_tile) issue_stage(pos, p.N, P, 0, st);
+    if (has_tile) issue_stage<STG>(pos, p.N, P, 0, st);
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     {
         // stage the table image: eight 16-byte loads in flight per lane (one L2 round trip per
@@ -548,19 +561,21 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     DIAG(unsigned long long d_nmov = 0, d_ntile = 0; unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
     if (has_tile) {
         // prologue: the rest of the first tile's features, nothing to overlap with yet
-        put_stage(pack_stage(P, 0, st), 0, b0, b1, b2, b3);
-        // no accumulators are live yet, so four stages (64 loads) share one round trip
+        put_stage<STG>(pack_stage<STG>(P, 0, st), 0, b0, b1, b2, b3);
+        // no accumulators are live yet, so 64 loads share one round trip
 #pragma unroll 1
-        for (int h0 = 1; h0 < nstages; h0 += 4) {
-            uint32_t s0[kStage], s1[kStage], s2[kStage], s3[kStage];
-            issue_stage(pos, p.N, P, h0, s0);
-            if (h0 + 1 < nstages) issue_stage(pos, p.N, P, h0 + 1, s1);
-            if (h0 + 2 < nstages) issue_stage(pos, p.N, P, h0 + 2, s2);
-            if (h0 + 3 < nstages) issue_stage(pos, p.N, P, h0 + 3, s3);
-            put_stage(pack_stage(P, h0, s0), h0, b0, b1, b2, b3);
-            if (h0 + 1 < nstages) put_stage(pack_stage(P, h0 + 1, s1), h0 + 1, b0, b1, b2, b3);
-            if (h0 + 2 < nstages) put_stage(pack_stage(P, h0 + 2, s2), h0 + 2, b0, b1, b2, b3);
-            if (h0 + 3 < nstages) put_stage(pack_stage(P, h0 + 3, s3), h0 + 3, b0, b1, b2, b3);
+        for (int h0 = 1; h0 < nstages; h0 += 64 / STG) {
+            uint32_t s0[STG], s1[STG], s2[STG], s3[STG];
+#pragma unroll
+            for (int u = 0; u < STG; ++u) { s0[u] = 0; s1[u] = 0; s2[u] = 0; s3[u] = 0; }
+            issue_stage<STG>(pos, p.N, P, h0, s0);
+            if (h0 + 1 < nstages) issue_stage<STG>(pos, p.N, P, h0 + 1, s1);
+            if (STG == 16 && h0 + 2 < nstages) issue_stage<STG>(pos, p.N, P, h0 + 2, s2);
+            if (STG == 16 && h0 + 3 < nstages) issue_stage<STG>(pos, p.N, P, h0 + 3, s3);
+            put_stage<STG>(pack_stage<STG>(P, h0, s0), h0, b0, b1, b2, b3);
+            if (h0 + 1 < nstages) put_stage<STG>(pack_stage<STG>(P, h0 + 1, s1), h0 + 1, b0, b1, b2, b3);
+            if (STG == 16 && h0 + 2 < nstages) put_stage<STG>(pack_stage<STG>(P, h0 + 2, s2), h0 + 2, b0, b1, b2, b3);
+            if (STG == 16 && h0 + 3 < nstages) put_stage<STG>(pack_stage<STG>(P, h0 + 3, s3), h0 + 3, b0, b1, b2, b3);
         }
         int zo = a.z_in ? a.z_in[pos.ic] : -1;
         asm volatile("" : "+v"(zo));  // land it before the pipeline starts: no load may be
@@ -591,12 +606,12 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double acc_own = 0.0;
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
-                if (has_next) issue_stage(npos, p.N, P, h, st);
+                if (has_next) issue_stage<STG>(npos, p.N, P, h, st);
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
-                const int g_hi = G < h * 4 + 4 ? G : h * 4 + 4;
+                const int g_hi = G < (h + 1) * GPS ? G : (h + 1) * GPS;
 #pragma unroll 1
-                for (int g = h * 4; g < g_hi; ++g) {
+                for (int g = h * GPS; g < g_hi; ++g) {
                     const unsigned nib = nibble_of(g, b0, b1, b2, b3);
                     const volatile lds_f64* row = Tp + ((size_t)g * KT * kGroupM + nib);
                     double own = 0.0;
@@ -614,7 +629,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                     if (has_minus) acc_own = acc_own + own;
                 }
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_score += n_ - d_t; d_t = n_; })
-                if (has_next) put_stage(pack_stage(P, h, st), h, n0, n1, n2, n3);
+                if (has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_pack += n_ - d_t; d_t = n_; })
             }
             // scores; the observation's own cluster is scored without itself
