@@ -104,6 +104,9 @@ struct bmm_chain {
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
+    bool generic = false;         // shape beyond the resident kernel: tables from global memory
+    double* dScratch = nullptr;   // generic path: per-thread score columns
+    int64_t scratch_stride = 0;
     size_t lds_bytes = 0;
     resample_fn fn = nullptr;
 
@@ -187,6 +190,7 @@ int chain_alloc(bmm_chain* c) {
     HIP_TRY(hipMalloc(&c->dTab, (size_t)layout_of(c).doubles() * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dPi, (size_t)p.K * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dTheta, (size_t)p.K * p.P * sizeof(double)));
+    if (c->generic) HIP_TRY(hipMalloc(&c->dScratch, (size_t)c->scratch_stride * p.Kc * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->dNk, 0, nn, c->stream));
     HIP_TRY(hipMemsetAsync(c->dDNk, 0, nn, c->stream));
     HIP_TRY(hipMemsetAsync(c->dS, 0, ns, c->stream));
@@ -208,7 +212,11 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     a.X = c->dX; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
     const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
-    const int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
+    int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
+    if (c->generic) {
+        const int64_t maxb = c->scratch_stride / 256;
+        grid = (int)(ntiles < maxb ? ntiles : maxb);
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof) {
         if (c->ev_used + 2 > c->ev.size()) {
@@ -221,7 +229,11 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
         c->ev_used += 2;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    hipLaunchKernelGGL(c->fn, dim3(grid), dim3(c->NT), c->lds_bytes, c->stream, c->p, a);
+    if (c->generic)
+        hipLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, c->p, a, c->dScratch,
+                           c->scratch_stride);
+    else
+        hipLaunchKernelGGL(c->fn, dim3(grid), dim3(c->NT), c->lds_bytes, c->stream, c->p, a);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
     return BMM_OK;
@@ -292,8 +304,12 @@ int chain_start(bmm_chain* c) {
                                    c->stream));
         const size_t hb = ((size_t)p.K * p.P + p.K) * sizeof(int32_t);
         const int64_t nt = (p.N + 255) / 256;
-        hipLaunchKernelGGL(k_count_labels, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), hb, c->stream, p,
-                           c->dX, row0, c->dDNk, c->dDS);
+        if (c->generic)
+            hipLaunchKernelGGL(k_count_labels_generic, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0,
+                               c->stream, p, c->dX, row0, c->dDNk, c->dDS);
+        else
+            hipLaunchKernelGGL(k_count_labels, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), hb, c->stream,
+                               p, c->dX, row0, c->dDNk, c->dDS);
         HIP_TRY(hipGetLastError());
     } else if (explicit_params(p.mode)) {
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
@@ -309,7 +325,6 @@ int check_common(int64_t N, int P, int K, double beta, double gamma) {
     if (P < 1) return set_err(BMM_E_ARG, "P must be >= 1");
     if (K < 1) return set_err(BMM_E_ARG, "K must be >= 1");
     if (!(beta > 0.0) || !(gamma > 0.0)) return set_err(BMM_E_ARG, "beta and gamma must be > 0");
-    if (P > kMaxP) return set_err(BMM_E_UNSUPPORTED, "P = %d exceeds %d features", P, kMaxP);
     return BMM_OK;
 }
 
@@ -357,42 +372,55 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     c->device = device;
     c->batch = batch <= 0 ? default_batch(sampler, N) : (batch > N ? N : batch);
     if (explicit_params(sampler)) c->batch = N;
-    if (p.KT < 0) {
+    if (p.Kc > kMaxCatsAny) {
         delete c;
-        return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build tabulates on chip", p.Kc, kMaxCats);
+        return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build supports", p.Kc, kMaxCatsAny);
     }
-    c->NT = threads_for(p.KT);
-    const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
-    c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
-    if (c->lds_bytes > lds_max && !explicit_params(p.mode)) {  // second tier: own-cluster tables stay in L2
+    const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
+    c->generic = p.KT < 0 || P > kMaxP || getenv("BMM_DEBUG_GENERIC") != nullptr;
+    if (!c->generic) {
+        c->NT = threads_for(p.KT);
+        c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
+        if (c->lds_bytes > lds_max && !explicit_params(p.mode)) {  // second tier: own-cluster tables stay in L2
+            c->minus_in_lds = 0;
+            c->lds_bytes = (size_t)layout_of(c).head() * sizeof(double) + hist_bytes;
+        }
+        if (c->lds_bytes > lds_max) c->generic = true;  // third tier: nothing resident
+    }
+    if (c->generic) {
+        // any shape: tables gathered from global memory, scores in a scratch column per thread
+        p.KT = (p.Kc + 3) / 4 * 4;
+        c->NT = 256;
+        c->lds_bytes = 0;
         c->minus_in_lds = 0;
-        c->lds_bytes = (size_t)layout_of(c).head() * sizeof(double) + hist_bytes;
+        int64_t threads = (int64_t)256 * 1024;
+        const int64_t cap = ((int64_t)256 << 20) / ((int64_t)p.Kc * 8);  // <= 256 MiB of scratch
+        if (threads > cap) threads = cap / 256 * 256;
+        if (threads < 256) threads = 256;
+        c->scratch_stride = threads;
+        c->grid_max = (int)(threads / 256);
+    } else {
+        c->fn = resample_kernel(p.KT, explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2));
+        if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
+            const int nt = atoi(dbg);
+            resample_fn f = nullptr;
+            if (!explicit_params(p.mode) && c->minus_in_lds)
+                f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
+            if (f) { c->fn = f; c->NT = nt; }
+        }
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        int per_cu = 0;
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c->fn), c->NT, c->lds_bytes);
+        if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
+        if (per_cu < 1) per_cu = 1;
+        c->grid_max = per_cu * prop.multiProcessorCount;
     }
-    if (c->lds_bytes > lds_max) {
-        const size_t need = c->lds_bytes;
-        delete c;
-        return set_err(BMM_E_UNSUPPORTED, "K = %d, P = %d need %zu bytes of LDS tables; the CU has %zu", K, P, need, lds_max);
-    }
-    c->fn = resample_kernel(p.KT, explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2));
-    if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
-        const int nt = atoi(dbg);
-        resample_fn f = nullptr;
-        if (!explicit_params(p.mode) && c->minus_in_lds)
-            f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
-        if (f) { c->fn = f; c->NT = nt; }
-    }
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-    int per_cu = 0;
-    if (e == hipSuccess)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c->fn), c->NT, c->lds_bytes);
-    if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
-    if (per_cu < 1) per_cu = 1;
-    c->grid_max = per_cu * prop.multiProcessorCount;
     if (batch <= 0 && !explicit_params(sampler)) {
         // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
         const int64_t round = (int64_t)c->grid_max * c->NT;
@@ -423,7 +451,7 @@ void bmm_chain_destroy(bmm_chain* c) {
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
-                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace};
+                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace, c->dScratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -28,8 +28,9 @@ namespace bmm {
 
 typedef __attribute__((address_space(3))) double lds_f64;  // LDS-qualified, keeps ds_read under volatile
 
-constexpr int kMaxP = 128;      // 4 bit-words per observation
-constexpr int kMaxCats = 64;    // clusters (+ the DP's new-cluster option)
+constexpr int kMaxP = 128;      // fast path: 4 bit-words per observation
+constexpr int kMaxCats = 64;    // fast path: clusters (+ the DP's new-cluster option)
+constexpr int kMaxCatsAny = 1024;  // generic path
 
 enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2, MODE_FULL = 3 };
 // the two samplers that carry explicit (pi, theta) and resample z | pi, theta in one exact batch
@@ -72,12 +73,13 @@ struct ChainParams {
 // Table construction: one workgroup per category.  For the counting samplers it first
 // folds the pending integer deltas of its cluster into the statistics.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void write_group_tables(const double* e1, const double* e0, int P, int G,
+// e1/e0 hold the `pc` features of one chunk; its `gc` groups start at global group g0
+__device__ __forceinline__ void write_group_tables(const double* e1, const double* e0, int pc, int g0, int gc,
                                                    int KT, int k, double* T) {
-    for (int idx = threadIdx.x; idx < G * kGroupM; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < gc * kGroupM; idx += blockDim.x) {
         const int g = idx / kGroupM;
         const unsigned m = idx % kGroupM;
-        T[(g * KT + k) * kGroupM + m] = group_entry(e1, e0, g, P, m);
+        T[((size_t)(g0 + g) * KT + k) * kGroupM + m] = group_entry(e1, e0, g, pc, m);
     }
 }
 
@@ -106,25 +108,30 @@ __global__ __launch_bounds__(128) void k_count_tables(ChainParams p, int32_t* __
     const double bg = p.beta + p.gamma;
     const double den_p = n > 0 ? log_(bg + (double)n) : 0.0;
     const double den_m = n > 1 ? log_(bg + (double)(n - 1)) : 0.0;
-    for (int d = threadIdx.x; d < P; d += blockDim.x) {
-        double a1 = 0.0, a0 = 0.0, b1 = 0.0, b0 = 0.0;
-        if (is_label) {
-            const int32_t s = S[k * P + d] + dS[k * P + d];
-            S[k * P + d] = s; dS[k * P + d] = 0;
-            if (n > 0) {
-                a1 = term_x1(p.beta, s, den_p);
-                a0 = term_x0(p.gamma, n, s, den_p);
+    for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
+        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
+        for (int dl = threadIdx.x; dl < pc; dl += blockDim.x) {
+            const int d = c0 + dl;
+            double a1 = 0.0, a0 = 0.0, b1 = 0.0, b0 = 0.0;
+            if (is_label) {
+                const int32_t s = S[(size_t)k * P + d] + dS[(size_t)k * P + d];
+                S[(size_t)k * P + d] = s; dS[(size_t)k * P + d] = 0;
+                if (n > 0) {
+                    a1 = term_x1(p.beta, s, den_p);
+                    a0 = term_x0(p.gamma, n, s, den_p);
+                }
+                if (n > 1) {
+                    b1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
+                    b0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
+                }
             }
-            if (n > 1) {
-                b1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
-                b0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
-            }
+            e1[dl] = a1; e0[dl] = a0; m1[dl] = b1; m0[dl] = b0;
         }
-        e1[d] = a1; e0[d] = a0; m1[d] = b1; m0[d] = b0;
+        __syncthreads();
+        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
+        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
+        __syncthreads();
     }
-    __syncthreads();
-    write_group_tables(e1, e0, P, p.G, p.KT, k, tab + L.tp());
-    write_group_tables(m1, m0, P, p.G, p.KT, k, tab + L.tm());
     if (threadIdx.x == 0) {
         double cp = neg_inf(), cm = neg_inf();
         const double ldN = log_((double)(p.N - 1) + alpha);
@@ -160,28 +167,33 @@ __global__ __launch_bounds__(128) void k_sb_theta_tables(ChainParams p, const in
     const TableLayout L{p.G, p.KT, 0};
     const int P = p.P, K = p.K;
     const bool is_label = k < K;
-    for (int d = threadIdx.x; d < P; d += blockDim.x) {
-        double a1 = 0.0, a0 = 0.0;
-        if (is_label) {
-            double th;
-            if (draw) {
-                const int32_t ck = Nk[k], V = S[k * P + d];
-                const uint32_t c0 = (uint32_t)(k * P + d);
-                Stream sa = make_stream(p.seed, c0, sweep, kStreamThetaA);
-                Stream sb = make_stream(p.seed, c0, sweep, kStreamThetaB);
-                th = rbeta_(p.beta + (double)V, (p.gamma + (double)ck) - (double)V, sa, sb);
-                theta[k + d * K] = th;
-            } else {
-                th = theta[k + d * K];
+    for (int c0 = 0; c0 < P; c0 += kMaxP) {
+        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
+        for (int dl = threadIdx.x; dl < pc; dl += blockDim.x) {
+            const int d = c0 + dl;
+            double a1 = 0.0, a0 = 0.0;
+            if (is_label) {
+                double th;
+                if (draw) {
+                    const int32_t ck = Nk[k], V = S[(size_t)k * P + d];
+                    const uint32_t c0s = (uint32_t)((size_t)k * P + d);
+                    Stream sa = make_stream(p.seed, c0s, sweep, kStreamThetaA);
+                    Stream sb = make_stream(p.seed, c0s, sweep, kStreamThetaB);
+                    th = rbeta_(p.beta + (double)V, (p.gamma + (double)ck) - (double)V, sa, sb);
+                    theta[k + (size_t)d * K] = th;
+                } else {
+                    th = theta[k + (size_t)d * K];
+                }
+                if (theta_trace) theta_trace[k + (size_t)d * K] = th;
+                a1 = log_(th);
+                a0 = log_(1.0 - th);
             }
-            if (theta_trace) theta_trace[k + d * K] = th;
-            a1 = log_(th);
-            a0 = log_(1.0 - th);
+            e1[dl] = a1; e0[dl] = a0;
         }
-        e1[d] = a1; e0[d] = a0;
+        __syncthreads();
+        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
+        __syncthreads();
     }
-    __syncthreads();
-    write_group_tables(e1, e0, P, p.G, p.KT, k, tab + L.tp());
     if (threadIdx.x == 0) {
         tab[L.cp() + k] = is_label ? log_(pi[k]) : neg_inf();
         tab[L.cm() + k] = neg_inf();
@@ -199,8 +211,8 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
                                                    double* __restrict__ pi_trace, int pi_stride,
                                                    double* __restrict__ alpha_trace,
                                                    int32_t* __restrict__ nk_trace) {
-    __shared__ int32_t ck[kMaxCats];
-    __shared__ double v[kMaxCats];
+    __shared__ int32_t ck[kMaxCatsAny];
+    __shared__ double v[kMaxCatsAny];
     const int K = p.K, P = p.P;
     for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
         S[idx] += dS[idx]; dS[idx] = 0;
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t*
                                                          double* __restrict__ theta_trace,
                                                          double* __restrict__ alpha_trace,
                                                          int32_t* __restrict__ nk_trace) {
-    __shared__ int32_t nk[kMaxCats];
+    __shared__ int32_t nk[kMaxCatsAny];
     const int K = p.K, P = p.P;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + dNk[k];
@@ -705,6 +717,130 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         atomicAdd(&a.diag[3], d_mov); atomicAdd(&a.diag[4], d_pro); atomicAdd(&a.diag[5], 1ull);
         atomicAdd(&a.diag[6], d_nmov);
     })
+}
+
+// ---------------------------------------------------------------------------------
+// Generic path: any P, up to kMaxCatsAny categories, no LDS residency.  Same arithmetic as
+// k_resample (group lookups in g order, C + sum, exp_nonpos, CDF walk in label order), with the
+// tables gathered from global memory (L2) and the scores kept in a per-thread scratch column
+// scr[k * stride + thread].  Clusters are accumulated sixteen at a time, X is re-read per chunk.
+// Slow next to the resident kernel; it exists so that every shape the reference accepts runs.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned nibble_from_x(const int32_t* X, int64_t N, int P, int64_t i, int g) {
+    unsigned nib = 0;
+#pragma unroll
+    for (int j = 0; j < kGroupW; ++j) {
+        const int d = g * kGroupW + j;
+        if (d < P) nib |= ((unsigned)X[i + (int64_t)d * N] & 1u) << j;
+    }
+    return nib;
+}
+
+__global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, ResampleArgs a, double* scr,
+                                                          int64_t stride) {
+    const bool has_minus = !explicit_params(p.mode);
+    const TableLayout L{p.G, p.KT, has_minus ? 1 : 0};
+    const double* const Tp = a.tab + L.tp();
+    const double* const Tm = a.tab + L.tm();
+    const double* const Cp = a.tab + L.cp();
+    const double* const Cm = a.tab + L.cm();
+    const int32_t* const NkT = reinterpret_cast<const int32_t*>(a.tab + L.nk());
+    const double* const ET = a.tab + L.et();
+    const int P = p.P, G = p.G, K = p.K, Kc = p.Kc, KT = p.KT;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double* const my = scr + gid;
+
+    int Kused = 0, new_label = -1;
+    if (p.mode == MODE_DP) {
+        for (int k = 0; k < K; ++k) {
+            if (NkT[k] > 0) ++Kused;
+            else if (new_label < 0) new_label = k;
+        }
+    }
+    for (int64_t i = a.lo + gid; i < a.hi; i += (int64_t)gridDim.x * blockDim.x) {
+        const int zo = a.z_in ? a.z_in[i] : -1;
+        const int zoc = zo < 0 ? 0 : zo;
+        double acc_own = 0.0;
+        if (has_minus)
+            for (int g = 0; g < G; ++g)
+                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nibble_from_x(a.X, p.N, P, i, g)];
+        double m = neg_inf();
+        for (int k0 = 0; k0 < Kc; k0 += 16) {
+            double acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + nibble_from_x(a.X, p.N, P, i, g);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (k0 + j < Kc) acc[j] = acc[j] + row[j * kGroupM];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = k0 + j;
+                if (k < Kc) {
+                    double sc = Cp[k] + acc[j];
+                    if (has_minus && k == zo) sc = Cm[zoc] + acc_own;
+                    my[(int64_t)k * stride] = sc;
+                    m = __builtin_fmax(m, sc);
+                }
+            }
+        }
+        double tot = 0.0;
+        for (int k = 0; k < Kc; ++k) {
+            const double w = exp_nonpos_tab(my[(int64_t)k * stride] - m, ET);
+            my[(int64_t)k * stride] = w;
+            tot = tot + w;
+        }
+        const double u = z_uniform(p.seed, (uint64_t)i, a.sweep);
+        const double t = u * tot;
+        double cdf = 0.0;
+        int cnt = 0, last = -1;
+        for (int k = 0; k < Kc; ++k) {
+            const double w = my[(int64_t)k * stride];
+            cdf = cdf + w;
+            cnt += t >= cdf ? 1 : 0;
+            last = w > 0.0 ? k : last;
+        }
+        int zn = cnt < Kc ? cnt : last;
+        if (!(m > neg_inf())) zn = zoc;
+        if (p.mode == MODE_DP && zn == K) {
+            const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
+            if (Kused - own_single < K - 1) {
+                zn = new_label;
+                if (own_single && (zn < 0 || zo < zn)) zn = zo;
+            } else {
+                int best = -1, bs = 0;
+                for (int k = 0; k < K; ++k) {
+                    const int sz = NkT[k] - (k == zo ? 1 : 0);
+                    if (sz > 0 && (best < 0 || sz < bs)) { best = k; bs = sz; }
+                }
+                zn = best >= 0 ? best : zoc;
+            }
+        }
+        a.z_out[i] = zn;
+        if (zn >= 0 && zn != zo) {
+            atomicAdd(&a.dNk[zn], 1);
+            if (zo >= 0) atomicAdd(&a.dNk[zo], -1);
+            for (int d = 0; d < P; ++d)
+                if (a.X[i + (int64_t)d * p.N] & 1) {
+                    atomicAdd(&a.dS[(size_t)zn * P + d], 1);
+                    if (zo >= 0) atomicAdd(&a.dS[(size_t)zo * P + d], -1);
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_labels_generic(ChainParams p, const int32_t* __restrict__ X,
+                                                              const int32_t* __restrict__ z, int32_t* dNk,
+                                                              int32_t* dS) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int zl = z[i];
+        if (zl < 0) continue;
+        atomicAdd(&dNk[zl], 1);
+        for (int d = 0; d < p.P; ++d)
+            if (X[i + (int64_t)d * p.N] & 1) atomicAdd(&dS[(size_t)zl * p.P + d], 1);
+    }
 }
 
 // S x N column-major 1-based output from the [S][N] 0-based device trace (tiled transpose)

@@ -34,7 +34,7 @@ extern "C" {
 
 #define BMM_OK 0
 #define BMM_E_ARG 1         /* invalid argument (message says which) */
-#define BMM_E_UNSUPPORTED 2 /* shape outside what the on-chip tables hold */
+#define BMM_E_UNSUPPORTED 2 /* more than 1024 categories */
 #define BMM_E_HIP 3         /* a HIP runtime call failed */
 #define BMM_E_NODEVICE 4    /* no usable gfx950 device */
 #define BMM_E_STATE 5       /* call sequence error on a resident chain */

@@ -243,15 +243,44 @@ def test_device_side_count_summaries_match_the_label_trace(oracle):
         assert np.array_equal(nk[s], np.bincount(want["z"][s] - 1, minlength=7))
 
 
+# ---------------------------------------------------------------- generic path (any shape)
+@pytest.mark.parametrize("N,P,K,batch", [(1200, 200, 5, 300), (900, 40, 100, 900), (700, 513, 3, 64),
+                                         (1500, 128, 60, 500)])
+def test_collapsed_beyond_the_resident_kernel(oracle, N, P, K, batch):
+    # P > 128, more than 64 clusters, or tables that do not fit in LDS: tables from global memory
+    X, _, _, _ = synth(N, P, 4, 31)
+    z0 = _z0(N, K, 2)
+    got = bm.gibbs_collapsed(X, 5, K, burnin=0, seed=13, batch=batch, initial_K=z0)
+    want = oracle.collapsed(X, z0, 5, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=13, batch=batch)
+    _same(got, want, ["z", "theta", "alpha"])
+
+
+def test_dp_and_explicit_samplers_beyond_the_resident_kernel(oracle):
+    X, _, _, _ = synth(800, 150, 4, 33)
+    got = bm.gibbs_dp(X, 6, burnin=1, maxK=80, seed=3, batch=100)
+    want = oracle.dp(X, 6, 0.0, 0.5, 0.5, 1, 1, 1, 80, seed=3, batch=100)
+    _same(got, want, ["z", "theta", "alpha"])
+    pi0, th0 = _sb_init(70, 150, 9)
+    got = bm.gibbs_stickbreaking(X, 5, 70, burnin=0, seed=4, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 5, 70, 0.0, 0.5, 0.5, 1, 1, 0, seed=4)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+    got = bm.gibbs_full(X, 5, 70, burnin=0, seed=4, initial_pi=pi0, initial_theta=th0)
+    want = oracle.full(X, pi0, th0, 5, 70, 0.0, 0.5, 0.5, 1, 1, 0, seed=4)
+    _same(got, want, ["z", "theta", "alpha", "pi"])
+
+
+def test_generic_path_equals_resident_path_on_an_ordinary_shape(oracle, monkeypatch):
+    X, _, _, _ = synth(3000, 33, 4, 35)
+    z0 = _z0(3000, 7, 6)
+    fast = bm.gibbs_collapsed(X, 6, 7, burnin=0, seed=21, batch=512, initial_K=z0)
+    monkeypatch.setenv("BMM_DEBUG_GENERIC", "1")
+    slow = bm.gibbs_collapsed(X, 6, 7, burnin=0, seed=21, batch=512, initial_K=z0)
+    _same(fast, slow, ["z", "theta", "alpha"])
+
+
 def test_unsupported_shapes_fail_loudly():
-    X = np.zeros((50, 200), dtype=np.int32)
-    with pytest.raises(bm.BmmError, match="exceeds"):
-        bm.gibbs_collapsed(X, 5, 2, seed=1)
-    X = np.zeros((50, 128), dtype=np.int32)
-    with pytest.raises(bm.BmmError, match="LDS"):
-        bm.gibbs_collapsed(X, 5, 60, seed=1)
     X = np.zeros((50, 10), dtype=np.int32)
     with pytest.raises(bm.BmmError, match="categories"):
-        bm.gibbs_collapsed(X, 5, 100, seed=1)
+        bm.gibbs_collapsed(X, 5, 2000, seed=1)
     with pytest.raises(bm.BmmError, match="initialK"):
         bm.gibbs_collapsed(X, 5, 2, seed=1, initial_K=np.full(50, 3))
