@@ -78,6 +78,25 @@ resample_fn resample_kernel_m(int kt) {
     }
     return nullptr;
 }
+// 256-thread variants: used when a batch is too small to give every CU a workgroup otherwise
+template <int MINUS>
+resample_fn resample_kernel_small(int kt) {
+    switch (kt) {
+        case 4: return k_resample<4, 256, MINUS, 16>;
+        case 8: return k_resample<8, 256, MINUS, 16>;
+        case 12: return k_resample<12, 256, MINUS, 16>;
+        case 16: return k_resample<16, 256, MINUS, 16>;
+        case 20: return k_resample<20, 256, MINUS, 16>;
+        case 24: return k_resample<24, 256, MINUS, 16>;
+        case 28: return k_resample<28, 256, MINUS, 16>;
+        case 32: return k_resample<32, 256, MINUS, 16>;
+        case 40: return k_resample<40, 256, MINUS, 16>;
+        case 48: return k_resample<48, 256, MINUS, 16>;
+        case 56: return k_resample<56, 256, MINUS, 16>;
+        case 64: return k_resample<64, 256, MINUS, 16>;
+    }
+    return nullptr;
+}
 // experiment hook (BMM_DEBUG_THREADS=768|512): the KT <= 20 kernels at a smaller workgroup
 template <int NT>
 resample_fn resample_kernel_dbg(int kt) {
@@ -420,6 +439,18 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
         if (per_cu < 1) per_cu = 1;
         c->grid_max = per_cu * prop.multiProcessorCount;
+        // a batch that cannot give every CU a workgroup runs on 256-thread workgroups instead, when the
+        // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
+        const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
+        if (tiles < prop.multiProcessorCount && c->NT > 256 && c->lds_bytes * 4 <= lds_max &&
+            (explicit_params(p.mode) || c->minus_in_lds) &&
+            !getenv("BMM_DEBUG_THREADS")) {
+            resample_fn f = explicit_params(p.mode) ? resample_kernel_small<0>(p.KT) : resample_kernel_small<1>(p.KT);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+            int pc2 = 0;
+            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(f), 256, c->lds_bytes);
+            if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->grid_max = pc2 * prop.multiProcessorCount; }
+        }
     }
     if (batch <= 0 && !explicit_params(sampler)) {
         // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
