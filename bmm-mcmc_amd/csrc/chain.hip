@@ -259,7 +259,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
 }
 
 int launch_count_tables(bmm_chain* c) {
-    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(128), 0, c->stream, c->p, c->dNk, c->dS,
+    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(256), 0, c->stream, c->p, c->dNk, c->dS,
                        c->dDNk, c->dDS, c->dAlpha, c->dTab);
     HIP_TRY(hipGetLastError());
     return BMM_OK;

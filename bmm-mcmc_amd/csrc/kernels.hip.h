@@ -83,7 +83,7 @@ __device__ __forceinline__ void write_group_tables(const double* e1, const doubl
     }
 }
 
-__global__ __launch_bounds__(128) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
+__global__ __launch_bounds__(256) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
                                                       int32_t* __restrict__ S,
                                                       int32_t* __restrict__ dNk,
                                                       int32_t* __restrict__ dS,
@@ -108,26 +108,34 @@ __global__ __launch_bounds__(128) void k_count_tables(ChainParams p, int32_t* __
     const double bg = p.beta + p.gamma;
     const double den_p = n > 0 ? log_(bg + (double)n) : 0.0;
     const double den_m = n > 1 ? log_(bg + (double)(n - 1)) : 0.0;
+    // 256 threads: the lower half computes the full-statistics terms of feature d, the upper half
+    // its "minus self" terms (two logs each instead of four in sequence)
+    const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
     for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
         const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
-        for (int dl = threadIdx.x; dl < pc; dl += blockDim.x) {
+        if (dl < pc) {
             const int d = c0 + dl;
-            double a1 = 0.0, a0 = 0.0, b1 = 0.0, b0 = 0.0;
+            double t1 = 0.0, t0 = 0.0;
             if (is_label) {
                 const int32_t s = S[(size_t)k * P + d] + dS[(size_t)k * P + d];
-                S[(size_t)k * P + d] = s; dS[(size_t)k * P + d] = 0;
-                if (n > 0) {
-                    a1 = term_x1(p.beta, s, den_p);
-                    a0 = term_x0(p.gamma, n, s, den_p);
-                }
-                if (n > 1) {
-                    b1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
-                    b0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
+                if (half == 0) {
+                    if (n > 0) {
+                        t1 = term_x1(p.beta, s, den_p);
+                        t0 = term_x0(p.gamma, n, s, den_p);
+                    }
+                } else if (n > 1) {
+                    t1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
+                    t0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
                 }
             }
-            e1[dl] = a1; e0[dl] = a0; m1[dl] = b1; m0[dl] = b0;
+            if (half == 0) { e1[dl] = t1; e0[dl] = t0; } else { m1[dl] = t1; m0[dl] = t0; }
         }
-        __syncthreads();
+        __syncthreads();  // both halves have read S + dS before either is rewritten
+        if (half == 0 && dl < pc && is_label) {
+            const int d = c0 + dl;
+            S[(size_t)k * P + d] += dS[(size_t)k * P + d];
+            dS[(size_t)k * P + d] = 0;
+        }
         write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
         write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
         __syncthreads();
