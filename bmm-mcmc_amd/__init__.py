@@ -243,6 +243,22 @@ class Chain:
     def sweeps(self, n):
         _capi.check(_capi.lib().bmm_chain_sweeps(self._h, _C.c_int(n)))
 
+    # -- one chain over several ranks (stick-breaking / full): see multi.ShardedChain
+    def set_shard(self, N_total, first_row):
+        _capi.check(_capi.lib().bmm_chain_set_shard(self._h, _C.c_int64(N_total), _C.c_int64(first_row)))
+
+    def shard_resample(self):
+        _capi.check(_capi.lib().bmm_chain_shard_resample(self._h))
+
+    def shard_deltas(self):
+        """Device addresses of the int32 statistic deltas (dNk: K, dS: K*P) to be summed over ranks."""
+        a, b = _C.c_void_p(), _C.c_void_p()
+        _capi.check(_capi.lib().bmm_chain_shard_deltas(self._h, _C.byref(a), _C.byref(b)))
+        return a.value, b.value
+
+    def shard_finish(self):
+        _capi.check(_capi.lib().bmm_chain_shard_finish(self._h))
+
     def sweeps_counts(self, n):
         """n more sweeps; returns the (n, K) cluster sizes after each, computed on the device."""
         out = _np.zeros((n, self.K), dtype=_np.int32)

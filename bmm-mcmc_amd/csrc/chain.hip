@@ -123,6 +123,7 @@ struct bmm_chain {
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
+    bool sharded = false, shard_open = false;  // one chain over several ranks (explicit-parameter samplers)
     bool generic = false;         // shape beyond the resident kernel: tables from global memory
     double* dScratch = nullptr;   // generic path: per-thread score columns
     int64_t scratch_stride = 0;
@@ -266,7 +267,8 @@ int launch_count_tables(bmm_chain* c) {
 }
 
 // one sweep (index j >= 1) enqueued on the stream
-int enqueue_sweep(bmm_chain* c, int j) {
+// phase 0: whole sweep; 1: z-resample only; 2: parameter draws and tables only (sharded chains)
+int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
     const ChainParams& p = c->p;
     const int32_t* zin = (p.mode != MODE_COLLAPSED && j == 1) ? nullptr : label_row(c, j - 1);
     int32_t* zout = label_row(c, j);
@@ -276,8 +278,11 @@ int enqueue_sweep(bmm_chain* c, int j) {
     double* al_tr = rec ? c->dAlphaTrace + s : nullptr;
     int32_t* nk_tr = c->dNkTrace ? c->dNkTrace + (size_t)(j - c->nk_trace_base) * p.K : nullptr;
     if (explicit_params(p.mode)) {
-        int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
-        if (rc) return rc;
+        if (phase != 2) {
+            int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
+            if (rc) return rc;
+        }
+        if (phase == 1) return BMM_OK;  // sharded chain: the caller all-reduces the deltas now
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
                            al_tr, nk_tr);
@@ -382,7 +387,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     bmm_chain* c = new (std::nothrow) bmm_chain();
     if (!c) return set_err(BMM_E_ARG, "out of host memory");
     ChainParams& p = c->p;
-    p.mode = sampler; p.N = N; p.P = P; p.G = (P + kGroupW - 1) / kGroupW; p.K = K;
+    p.mode = sampler; p.N = N; p.Ntot = N; p.obs0 = 0; p.P = P; p.G = (P + kGroupW - 1) / kGroupW; p.K = K;
     p.Kc = sampler == BMM_SAMPLER_DP ? K + 1 : K;
     p.KT = pick_kt(p.Kc);
     p.beta = beta; p.gamma = gamma; p.a = a; p.b = b; p.seed = seed;
@@ -552,6 +557,7 @@ int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* t
 int bmm_chain_sweeps(bmm_chain* c, int n) {
     if (!c) return set_err(BMM_E_ARG, "null chain");
     if (n < 0) return set_err(BMM_E_ARG, "n must be >= 0");
+    if (c->sharded && n > 0) return set_err(BMM_E_STATE, "a sharded chain advances by bmm_chain_shard_resample / _finish");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->started) {
         int rc = chain_start(c);
@@ -562,6 +568,52 @@ int bmm_chain_sweeps(bmm_chain* c, int n) {
         if (rc) return rc;
         c->sweep++;
     }
+    return BMM_OK;
+}
+
+int bmm_chain_set_shard(bmm_chain* c, int64_t N_total, int64_t first_row) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    if (!explicit_params(c->p.mode))
+        return set_err(BMM_E_UNSUPPORTED, "only the stick-breaking and full samplers shard exactly over observations");
+    if (first_row < 0 || N_total < first_row + c->p.N) return set_err(BMM_E_ARG, "shard [first_row, first_row + N) lies outside N_total");
+    c->p.Ntot = N_total;
+    c->p.obs0 = first_row;
+    c->sharded = true;
+    return BMM_OK;
+}
+
+int bmm_chain_shard_resample(bmm_chain* c) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (!explicit_params(c->p.mode)) return set_err(BMM_E_UNSUPPORTED, "not a shardable sampler");
+    if (c->shard_open) return set_err(BMM_E_STATE, "previous sweep not finished (bmm_chain_shard_finish)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->started) {
+        int rc = chain_start(c);
+        if (rc) return rc;
+    }
+    int rc = enqueue_sweep(c, c->sweep + 1, 1);
+    if (rc) return rc;
+    c->shard_open = true;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the deltas are complete: safe to reduce on any stream
+    return BMM_OK;
+}
+
+int bmm_chain_shard_deltas(bmm_chain* c, void** dNk, void** dS) {
+    if (!c || !dNk || !dS) return set_err(BMM_E_ARG, "null argument");
+    *dNk = c->dDNk;
+    *dS = c->dDS;
+    return BMM_OK;
+}
+
+int bmm_chain_shard_finish(bmm_chain* c) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (!c->shard_open) return set_err(BMM_E_STATE, "no sweep open (bmm_chain_shard_resample)");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = enqueue_sweep(c, c->sweep + 1, 2);
+    if (rc) return rc;
+    c->sweep++;
+    c->shard_open = false;
     return BMM_OK;
 }
 

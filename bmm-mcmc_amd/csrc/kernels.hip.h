@@ -59,7 +59,9 @@ struct TableLayout {
 
 struct ChainParams {
     int mode;           // MODE_*
-    int64_t N;
+    int64_t N;          // observations held by this chain object (a shard, or all of them)
+    int64_t Ntot;       // observations of the whole chain (= N unless the chain is sharded over ranks)
+    int64_t obs0;       // global index of local observation 0 (keys the per-observation Philox counter)
     int P, G;
     int K;              // labels (K or maxK)
     int Kc;             // categories = K (+1 for DP)
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_count_tables(ChainParams p, int32_t* __
     }
     if (threadIdx.x == 0) {
         double cp = neg_inf(), cm = neg_inf();
-        const double ldN = log_((double)(p.N - 1) + alpha);
+        const double ldN = log_((double)(p.Ntot - 1) + alpha);
         if (is_label) {
             if (p.mode == MODE_COLLAPSED) {
                 const double ak = div_(alpha, (double)p.K);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
         }
         double alpha_new = alpha_prev;
         if (p.sample_alpha) {
-            alpha_new = update_alpha_(alpha_prev, p.a, p.b, (double)p.N, viable, p.seed, sweep);
+            alpha_new = update_alpha_(alpha_prev, p.a, p.b, (double)p.Ntot, viable, p.seed, sweep);
             *alpha_ptr = alpha_new;
         }
         if (alpha_trace) *alpha_trace = alpha_new;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t*
         if (p.sample_alpha) {
             int Kc = K;
             if (p.mode == MODE_DP) { Kc = 0; for (int k = 0; k < K; ++k) Kc += nk[k] > 0; }
-            al = update_alpha_(al, p.a, p.b, (double)p.N, Kc, p.seed, sweep);
+            al = update_alpha_(al, p.a, p.b, (double)p.Ntot, Kc, p.seed, sweep);
             *alpha_ptr = al;
         }
         if (alpha_trace) *alpha_trace = al;
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 tot = tot + w;
                 if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries
             }
-            const double u = z_uniform(p.seed, (uint64_t)pos.ic, a.sweep);
+            const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + pos.ic), a.sweep);
             const double t = u * tot;
             double cdf = 0.0;
             int cnt = 0;
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
             my[(int64_t)k * stride] = w;
             tot = tot + w;
         }
-        const double u = z_uniform(p.seed, (uint64_t)i, a.sweep);
+        const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + i), a.sweep);
         const double t = u * tot;
         double cdf = 0.0;
         int cnt = 0, last = -1;

@@ -102,3 +102,53 @@ def _hip_chain(sampler, X, K, nsweeps, seed, batch, **prior):
             ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
         ch.sweeps(nsweeps)
         return ch.labels()
+
+
+# ---------------------------------------------------------------- one chain over several ranks
+class _DeviceInts:
+    """int32 device memory owned by the library, exposed through the CUDA array interface."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def device_ints(ptr, n, device):
+    """Zero-copy torch view of `n` int32 at device address `ptr`."""
+    import torch
+    return torch.as_tensor(_DeviceInts(ptr, n), device=device)
+
+
+class ShardedChain:
+    """One stick-breaking / full chain whose observations are split over the ranks of the job
+    (SURVEY.md section 8 row f4).  Rank r holds rows [first_row, first_row + n_local) of the
+    N_total; every rank passes the SAME seed and initial (pi, theta).  Per sweep: local z-resample,
+    one all-reduce of the K*(P+1) integer statistic deltas (RCCL with the nccl backend), then the
+    parameter draws, which come out identical on every rank."""
+
+    def __init__(self, sampler, X_local, N_total, first_row, K, pi0, theta0, seed, device=0, **prior):
+        import torch
+        from . import Chain
+        P, n_local = X_local.shape
+        self.K, self.P = int(K), int(P)
+        self.dev = torch.device("cuda", device)
+        self.chain = Chain(sampler, n_local, P, K, seed=seed, device=device, **prior)
+        self.chain.set_data_device(X_local.data_ptr(), keepalive=X_local)
+        self.chain.set_shard(N_total, first_row)
+        self.chain.set_initial_params(pi0, theta0)
+        a, b = self.chain.shard_deltas()
+        self.d_nk = device_ints(a, K, self.dev)
+        self.d_s = device_ints(b, K * P, self.dev)
+
+    def sweep(self):
+        import torch
+        import torch.distributed as dist
+        self.chain.shard_resample()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.d_nk)
+            dist.all_reduce(self.d_s)
+            torch.cuda.synchronize(self.dev)
+        self.chain.shard_finish()
+
+    def close(self):
+        self.chain.close()

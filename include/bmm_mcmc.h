@@ -111,6 +111,19 @@ int bmm_chain_get_labels(bmm_chain* c, int32_t* z1);
 int bmm_chain_get_counts(bmm_chain* c, int32_t* Nk /*K*/, int32_t* S /*K*P, S[k*P+d]*/);
 int bmm_chain_get_alpha(bmm_chain* c, double* alpha);
 int bmm_chain_get_params(bmm_chain* c, double* pi /*K*/, double* theta /*K x P colmajor*/);
+/* ---- one chain sharded over several ranks --------------------
+ * Exact for the stick-breaking and full samplers, whose z-step is independent across
+ * observations given (pi, theta): each rank holds rows [first_row, first_row + N) of the N_total
+ * and resamples them; the K*(P+1) integer statistic deltas are summed over ranks (one RCCL
+ * all-reduce, done by the caller on the device pointers below); every rank then draws the same
+ * pi, theta, alpha, because the Philox streams are keyed by (seed, global index) only.
+ *   set_shard once before the first sweep; per sweep: shard_resample (returns with the deltas
+ *   complete), all-reduce *dNk (K int32) and *dS (K*P int32) in place, shard_finish. */
+int bmm_chain_set_shard(bmm_chain* c, int64_t N_total, int64_t first_row);
+int bmm_chain_shard_resample(bmm_chain* c);
+int bmm_chain_shard_deltas(bmm_chain* c, void** dNk, void** dS);
+int bmm_chain_shard_finish(bmm_chain* c);
+
 /* HIP-event timing of the z-resample kernel on the chain's own stream: turn on, run
  * sweeps, sync, read total milliseconds and launch count since it was turned on */
 int bmm_chain_profile(bmm_chain* c, int enable);

@@ -243,6 +243,53 @@ def test_device_side_count_summaries_match_the_label_trace(oracle):
         assert np.array_equal(nk[s], np.bincount(want["z"][s] - 1, minlength=7))
 
 
+# ---------------------------------------------------------------- one chain over several ranks (row f4)
+@pytest.mark.parametrize("sampler", ["stickbreaking", "full"])
+def test_sharded_chain_equals_the_single_chain(oracle, sampler):
+    # two "virtual ranks" on one GPU: each holds half of the rows; the all-reduce of the statistic
+    # deltas is done by hand on the same device buffers RCCL would reduce
+    import torch
+    from bmm_mcmc_amd import multi
+    N, P, K, sweeps = 5001, 40, 9, 6
+    X, _, _, _ = synth(N, P, 4, 41)
+    pi0, th0 = _sb_init(K, P, 3)
+    cut = 2048
+    Xt = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()          # (P, N) = N x P column-major
+    shards = [Xt[:, :cut].contiguous(), Xt[:, cut:].contiguous()]
+    chains = [multi.ShardedChain(sampler, shards[0], N, 0, K, pi0, th0, seed=77),
+              multi.ShardedChain(sampler, shards[1], N, cut, K, pi0, th0, seed=77)]
+    for _ in range(sweeps):
+        for c in chains:
+            c.chain.shard_resample()
+        for name in ("d_nk", "d_s"):
+            tot = getattr(chains[0], name) + getattr(chains[1], name)
+            for c in chains:
+                getattr(c, name).copy_(tot)
+        torch.cuda.synchronize()
+        for c in chains:
+            c.chain.shard_finish()
+    z = np.concatenate([c.chain.labels() for c in chains])
+    pis = [c.chain.params() for c in chains]
+    alphas = [c.chain.alpha() for c in chains]
+    for c in chains:
+        c.close()
+    fn = oracle.stickbreaking if sampler == "stickbreaking" else oracle.full
+    want = fn(X, pi0, th0, sweeps + 1, K, 0.0, 0.5, 0.5, 1, 1, sweeps, seed=77)
+    assert np.array_equal(z, want["z"][0])
+    for pi, theta in pis:                                             # identical on both ranks
+        assert np.array_equal(pi, want["pi"][0]) and np.array_equal(theta, want["theta"][:, :, 0])
+    assert alphas[0] == alphas[1] == want["alpha"][0, 0]
+
+
+def test_sharding_is_refused_where_it_is_not_exact():
+    with bm.Chain("collapsed", 100, 5, 2, seed=1) as ch:
+        with pytest.raises(bm.BmmError, match="shard exactly"):
+            ch.set_shard(200, 0)
+    with bm.Chain("stickbreaking", 100, 5, 4, seed=1) as ch:
+        with pytest.raises(bm.BmmError, match="outside N_total"):
+            ch.set_shard(150, 100)
+
+
 # ---------------------------------------------------------------- generic path (any shape)
 @pytest.mark.parametrize("N,P,K,batch", [(1200, 200, 5, 300), (900, 40, 100, 900), (700, 513, 3, 64),
                                          (1500, 128, 60, 500)])
