@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="override K (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / north-star side measurements")
+    ap.add_argument("--shard", action="store_true",
+                    help="ONE chain whose rows are split over the ranks (stick-breaking / full workloads "
+                         "only; strong scaling, one all-reduce of the statistics per sweep)")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     args = ap.parse_args()
@@ -112,6 +115,8 @@ def main():
              "X": X, "chain": ch}
         return m
 
+    if args.shard:
+        return bench_sharded(args, world, rank, local, dev, barrier)
     m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k)
     sampler, K, N, P, batch, shape = m["sampler"], m["K"], m["N"], m["P"], m["batch"], m["shape"]
     dt, kern_ms, kern_n, X, ch = m["dt"], m["kern_ms"], m["kern_n"], m["X"], m["chain"]
@@ -190,6 +195,50 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     return result
+
+
+def bench_sharded(args, world, rank, local, dev, barrier):
+    """One chain over all ranks: every rank builds the same synthetic
+    matrix from the same seed and keeps its slice of rows; value = sweeps/s of that single chain."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bmm_mcmc_amd import multi, synth
+    sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
+    if sampler not in ("stickbreaking", "full"):
+        raise SystemExit("--shard needs a stick-breaking or full workload (e.g. --workload c4)")
+    if args.n:
+        N = args.n
+    X, _ = synth.device_matrix(N, P, K_true, dseed, dev)      # same seed => same matrix on every rank
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    Xl = X[:, lo:hi].contiguous()
+    del X
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(1000)
+    pi0 = np.exp(rng.random(K))
+    ch = multi.ShardedChain(sampler, Xl, N, lo, K, pi0 / pi0.sum(), rng.random((K, P)), seed=1000, device=local)
+    for _ in range(args.burn + args.warmup):
+        ch.sweep()
+    ch.chain.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ch.sweep()
+    ch.chain.sync()
+    barrier()
+    dt = multi.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "gibbs_sweeps_per_s", "value": args.steps / dt, "unit": "sweeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, ONE chain sharded over %d GPU(s)" % (
+                args.workload, sampler, K, N, P, world), "rows_per_rank": hi - lo,
+                "collective": "all-reduce of %d int32 per sweep" % (K * (P + 1))}}))
+    ch.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
