@@ -259,6 +259,13 @@ class Chain:
     def shard_finish(self):
         _capi.check(_capi.lib().bmm_chain_shard_finish(self._h))
 
+    def sweep_probs(self):
+        """One more sweep; returns the (N, K) matrix of allocation probabilities it drew from (the
+        input of the reference's host-side relabelling)."""
+        out = _np.zeros((self.N, self.K), order="F")
+        _capi.check(_capi.lib().bmm_chain_sweep_probs(self._h, _capi.vp(out)))
+        return out
+
     def sweeps_counts(self, n):
         """n more sweeps; returns the (n, K) cluster sizes after each, computed on the device."""
         out = _np.zeros((n, self.K), dtype=_np.int32)

@@ -126,6 +126,8 @@ struct bmm_chain {
     bool sharded = false, shard_open = false;  // one chain over several ranks (explicit-parameter samplers)
     bool generic = false;         // shape beyond the resident kernel: tables from global memory
     double* dScratch = nullptr;   // generic path: per-thread score columns
+    double* dProbs = nullptr;     // sweep_probs: N x K probabilities of the sweep being run
+    bool probs_sweep = false;     // route this sweep through the generic kernel and emit dProbs
     int64_t scratch_stride = 0;
     size_t lds_bytes = 0;
     resample_fn fn = nullptr;
@@ -233,9 +235,12 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
     const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
     int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
-    if (c->generic) {
+    const bool use_generic = c->generic || c->probs_sweep;
+    if (use_generic) {
+        const int64_t nt256 = (hi - lo + 255) / 256;
         const int64_t maxb = c->scratch_stride / 256;
-        grid = (int)(ntiles < maxb ? ntiles : maxb);
+        grid = (int)(nt256 < maxb ? nt256 : maxb);
+        a.probs = c->probs_sweep ? c->dProbs : nullptr;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof) {
@@ -249,7 +254,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
         c->ev_used += 2;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    if (c->generic)
+    if (use_generic)
         hipLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, c->p, a, c->dScratch,
                            c->scratch_stride);
     else
@@ -487,7 +492,7 @@ void bmm_chain_destroy(bmm_chain* c) {
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
-                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace, c->dScratch};
+                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace, c->dScratch, c->dProbs};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -614,6 +619,30 @@ int bmm_chain_shard_finish(bmm_chain* c) {
     if (rc) return rc;
     c->sweep++;
     c->shard_open = false;
+    return BMM_OK;
+}
+
+int bmm_chain_sweep_probs(bmm_chain* c, double* probs_out) {
+    if (!c || !probs_out) return set_err(BMM_E_ARG, "null argument");
+    if (c->sharded) return set_err(BMM_E_STATE, "not available on a sharded chain");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->p.N * c->p.K * sizeof(double);
+    if (!c->dProbs) HIP_TRY(hipMalloc(&c->dProbs, bytes));
+    if (!c->dScratch) {  // a resident-kernel chain borrows the generic kernel for this sweep
+        int64_t threads = (int64_t)256 * 1024;
+        const int64_t cap = ((int64_t)256 << 20) / ((int64_t)c->p.Kc * 8);
+        if (threads > cap) threads = cap / 256 * 256;
+        if (threads < 256) threads = 256;
+        c->scratch_stride = threads;
+        HIP_TRY(hipMalloc(&c->dScratch, (size_t)threads * c->p.Kc * sizeof(double)));
+    }
+    HIP_TRY(hipMemsetAsync(c->dProbs, 0, bytes, c->stream));
+    c->probs_sweep = true;
+    int rc = bmm_chain_sweeps(c, 1);
+    c->probs_sweep = false;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(probs_out, c->dProbs, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
 }
 

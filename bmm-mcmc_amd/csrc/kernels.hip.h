@@ -332,6 +332,7 @@ struct ResampleArgs {
     int64_t lo, hi;        // batch [lo, hi)
     uint32_t sweep;
     int minus_in_lds;      // 1: the Tm tables were sized into LDS too
+    double* probs;         // generic kernel only: N x K column-major normalised probabilities, or null
     unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
 };
 
@@ -801,6 +802,14 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
             const double w = exp_nonpos_tab(my[(int64_t)k * stride] - m, ET);
             my[(int64_t)k * stride] = w;
             tot = tot + w;
+        }
+        if (a.probs) {
+            // the matrix the host relabelling consumes (collapsed_gibbs.cpp:162-172): by label; the DP's
+            // new-cluster mass goes under the label it would open (collapsed_gibbs_dp.cpp:193)
+            for (int k = 0; k < Kc; ++k) {
+                const int lbl = k < K ? k : new_label;
+                if (lbl >= 0) a.probs[i + (int64_t)lbl * p.N] = div_(my[(int64_t)k * stride], tot);
+            }
         }
         const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + i), a.sweep);
         const double t = u * tot;

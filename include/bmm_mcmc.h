@@ -111,6 +111,14 @@ int bmm_chain_get_labels(bmm_chain* c, int32_t* z1);
 int bmm_chain_get_counts(bmm_chain* c, int32_t* Nk /*K*/, int32_t* S /*K*P, S[k*P+d]*/);
 int bmm_chain_get_alpha(bmm_chain* c, double* alpha);
 int bmm_chain_get_params(bmm_chain* c, double* pi /*K*/, double* theta /*K x P colmajor*/);
+/* One more sweep, also returning that sweep's allocation probabilities: probs_out is N x K
+ * column-major (host), row i = the normalised conditional observation i was drawn from, by label
+ * (the DP's new-cluster mass under the label it would open).  This is the matrix the reference
+ * stores for Stephens' relabelling (src/collapsed_gibbs.cpp:162-172, collapsed_gibbs_dp.cpp:190-200,
+ * stickbreaking.cpp:129-139) -- the hand-off for relabel = TRUE, whose batch/online steps stay on the
+ * host in the reference's own code.  Runs on the generic kernel; waits. */
+int bmm_chain_sweep_probs(bmm_chain* c, double* probs_out);
+
 /* ---- one chain sharded over several ranks --------------------
  * Exact for the stick-breaking and full samplers, whose z-step is independent across
  * observations given (pi, theta): each rank holds rows [first_row, first_row + N) of the N_total

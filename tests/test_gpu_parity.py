@@ -290,6 +290,34 @@ def test_sharding_is_refused_where_it_is_not_exact():
             ch.set_shard(150, 100)
 
 
+# ---------------------------------------------------------------- relabel hand-off (row f2)
+def test_sweep_probabilities_are_the_conditionals_the_draw_used(oracle):
+    X = load_dataset("K3_N1000_P5")[::4]                      # 250 observations
+    N, K = X.shape[0], 3
+    z0 = _z0(N, K, 5)
+    with bm.Chain("collapsed", N, 5, K, alpha=1.5, batch=N, seed=4) as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        z_before = ch.labels()
+        probs = ch.sweep_probs()
+        z_after = ch.labels()
+    want = oracle.collapsed(X, z0, 4, K, 1.5, 0.5, 0.5, 1, 1, 2, seed=4, batch=N)
+    assert np.array_equal(z_before, want["z"][0]) and np.array_equal(z_after, want["z"][1])
+    for i in range(N):                                        # batch = N: every row against the same state
+        _, norm = oracle.collapsed_cond(X, z_before, i, K, 1.5, 0.5, 0.5, spec=True)
+        assert np.array_equal(probs[i], norm)
+    np.testing.assert_allclose(probs.sum(axis=1), 1.0, rtol=0, atol=1e-15)
+    pi0, th0 = _sb_init(4, 5, 1)
+    with bm.Chain("stickbreaking", N, 5, 4, alpha=1.0, seed=4) as ch:
+        ch.set_data(X)
+        ch.set_initial_params(pi0, th0)
+        probs = ch.sweep_probs()
+    for i in (0, 17, N - 1):
+        _, norm = oracle.sb_cond(X, i, pi0, th0, spec=True)
+        assert np.array_equal(probs[i], norm)
+
+
 # ---------------------------------------------------------------- generic path (any shape)
 @pytest.mark.parametrize("N,P,K,batch", [(1200, 200, 5, 300), (900, 40, 100, 900), (700, 513, 3, 64),
                                          (1500, 128, 60, 500)])
