@@ -1,0 +1,80 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes, where the oracle is
+too slow to run: the integer sufficient statistics equal a recount from the labels, labels stay in
+range, the same seed gives the same chain, different seeds do not, pi sums to one.  torch is used
+only to build the synthetic matrix in HBM (as bench.py does) and to recount on the device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _recount(torch, X, z1, K):
+    """Nk and S[k, d] recomputed from 1-based labels with plain torch reductions."""
+    z = torch.as_tensor(z1.astype(np.int64) - 1, device=X.device)
+    Nk = torch.bincount(z, minlength=K)[:K]
+    P = X.shape[0]
+    S = torch.stack([torch.bincount(z, weights=X[d].to(torch.float64), minlength=K)[:K] for d in range(P)], dim=1)
+    return Nk.cpu().numpy(), S.cpu().numpy().astype(np.int64)
+
+
+def _chain(bm, synth, torch, name, seed, sweeps, **kw):
+    sampler, K, K_true, N, P, dseed = synth.WORKLOADS[name]
+    dev = torch.device("cuda", 0)
+    X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
+    ch = bm.Chain(sampler, N, P, K, seed=seed, **kw)
+    ch.set_data_device(X.data_ptr(), keepalive=X)
+    rng = np.random.default_rng(seed)
+    if sampler == "collapsed":
+        ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+    elif sampler == "stickbreaking":
+        pi0 = np.exp(rng.random(K))
+        ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+    ch.sweeps(sweeps)
+    return ch, X, (sampler, K, N, P)
+
+
+@pytest.mark.timeout(600)
+def test_c5_collapsed_K20_N1e7_P100_statistics_are_a_recount_of_the_labels():
+    import torch
+    import bmm_mcmc_amd as bm
+    from bmm_mcmc_amd import synth
+    ch, X, (_, K, N, P) = _chain(bm, synth, torch, "c5", 1000, 4)
+    z = ch.labels()
+    Nk, S = ch.counts()
+    ch.close()
+    assert z.min() >= 1 and z.max() <= K and Nk.sum() == N
+    Nk2, S2 = _recount(torch, X, z, K)
+    assert np.array_equal(Nk, Nk2) and np.array_equal(S, S2)
+    assert (S <= Nk[:, None]).all()
+    del X
+    # same seed -> same chain; another seed -> another chain (first million labels compared)
+    ch2, X2, _ = _chain(bm, synth, torch, "c5", 1000, 4)
+    z2 = ch2.labels()
+    ch2.close()
+    assert np.array_equal(z, z2)
+    del X2
+    ch3, X3, _ = _chain(bm, synth, torch, "c5", 1001, 4)
+    z3 = ch3.labels()
+    ch3.close()
+    assert not np.array_equal(z[:1000000], z3[:1000000])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_c3_dp_and_c4_stickbreaking_full_size_invariants(name):
+    import torch
+    import bmm_mcmc_amd as bm
+    from bmm_mcmc_amd import synth
+    ch, X, (sampler, K, N, P) = _chain(bm, synth, torch, name, 7, 5)
+    z = ch.labels()
+    Nk, S = ch.counts()
+    al = ch.alpha()
+    if sampler == "stickbreaking":
+        pi, theta = ch.params()
+        assert abs(pi.sum() - 1.0) < 1e-12 and (theta > 0).all() and (theta < 1).all()
+    ch.close()
+    assert z.min() >= 1 and z.max() <= K and Nk.sum() == N and al > 0
+    Nk2, S2 = _recount(torch, X, z, K)
+    assert np.array_equal(Nk, Nk2) and np.array_equal(S, S2)
+    if sampler == "dp":
+        assert (Nk > 0).sum() <= K - 1        # the truncation invariant K <= maxK - 1
