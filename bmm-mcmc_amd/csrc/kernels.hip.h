@@ -362,7 +362,7 @@ __device__ __forceinline__ TilePos tile_pos(const ResampleArgs& a, int64_t tile,
 // wave-uniform base + zero-extended 32-bit lane offset (global_load saddr form).
 // buffer form: the descriptor (SGPRs) carries the wave-uniform column base and is advanced
 // by the column stride between loads; the lane offset is one shared VGPR.  No per-load
-// address registers: the kStage loads of one stage are in flight from kStage + 1 VGPRs.
+// address registers: the STG loads of one stage are in flight from STG + 1 VGPRs.
 // STG = features per pipeline stage (16 or 32 = 4 or 8 lookup groups); template parameter below
 
 template <int STG>
@@ -509,8 +509,9 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #endif
 
 // The z-resample kernel.  Software pipeline per wave, two levels:
-//  * HBM: while tile t is scored, the 16 loads of feature stage h of tile t+1 are in
-//    flight; they are packed after lookup group 4h+3 and the loads of stage h+1 issued;
+//  * HBM: while tile t is scored, the STG loads of feature stage h of tile t+1 are in
+//    flight; they are issued at the top of outer iteration h and packed at its bottom, after the
+//    stage's own STG/4 lookup groups of tile t (nothing in flight is ever loop-carried);
 //  * LDS: the K lookups of a group are issued together and added as they return (volatile:
 //    one ds_read_b64 each -- the compiler would otherwise pair them into ds_read2_b64,
 //    which moves half the bytes per clock).
