@@ -12,8 +12,12 @@ The data matrix is generated in HBM on rank 0 and broadcast over RCCL (the only
 collective on this path); chains are independent, so scaling is weak.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the z-resample kernel, timed with HIP
-events on the chain's own stream inside the timed region; algorithmic bytes are
-N*(4P+8) per sweep (int32 X row + z read + z write).
+events on the chain's own stream inside the timed region.  Algorithmic bytes follow SURVEY.md
+section 8d for the layout ACTUALLY streamed: by default X is packed once into bit planes when
+it is handed over, so a sweep streams N*(4*ceil(P/32)+8) bytes (bit-plane words + z read + z
+write); the int32-equivalent figure N*(4P+8) is reported only as a labelled secondary, and the
+kernel that streams the int32 matrix as R hands it over (--x-layout int32) is measured beside
+the headline in `other_workloads`.
 `cpu_baseline` is the oracle's sufficient-statistics chain (same batch semantics) on the
 host cores of this box, on a bounded row sample, scaled to sweeps/s at the workload's N.
 """
@@ -42,6 +46,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
     ap.add_argument("--k", type=int, default=0, help="override K (debug)")
+    ap.add_argument("--x-layout", default="bits", choices=["bits", "int32"],
+                    help="what the resample kernel streams: bit planes packed once at hand-over (default) "
+                         "or the int32 matrix as R hands it over")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / north-star side measurements")
     ap.add_argument("--shard", action="store_true",
@@ -73,7 +80,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, steps, warmup, burn, batch_arg, n_override=0, k_override=0):
+    def measure(workload, steps, warmup, burn, batch_arg, n_override=0, k_override=0, x_layout="bits"):
         """One chain per rank on `workload`; returns timing of `steps` sweeps (max over ranks)."""
         sampler, K, K_true, N, P, dseed = synth.WORKLOADS[workload]
         if n_override:
@@ -90,7 +97,7 @@ def main():
         torch.cuda.synchronize()
         seed = multi.chain_seed(1000, rank)  # chain seeds 1000 + c
         ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
-                      batch=batch_arg if batch_arg > 0 else None, seed=seed, device=local)
+                      batch=batch_arg if batch_arg > 0 else None, seed=seed, device=local, x_layout=x_layout)
         ch.set_data_device(X.data_ptr(), keepalive=X)
         rng = np.random.default_rng(seed)
         if sampler == "collapsed":
@@ -112,24 +119,31 @@ def main():
         ch.profile(False)
         m = {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
              "dt": multi.max_over_ranks(t1 - t0), "kern_ms": multi.max_over_ranks(kern_ms), "kern_n": kern_n,
-             "X": X, "chain": ch}
+             "X": X, "chain": ch, "layout": ch.x_layout()}
         return m
+
+    def sweep_bytes(N, P, layout):
+        """bytes of the layout streamed + 4 B old label + 4 B new label, per observation."""
+        return N * ((4 * ((P + 31) // 32) if layout == "bits" else 4 * P) + 8)
 
     if args.shard:
         return bench_sharded(args, world, rank, local, dev, barrier)
-    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k)
+    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k, args.x_layout)
     sampler, K, N, P, batch, shape = m["sampler"], m["K"], m["N"], m["P"], m["batch"], m["shape"]
     dt, kern_ms, kern_n, X, ch = m["dt"], m["kern_ms"], m["kern_n"], m["X"], m["chain"]
 
     result = None
     if rank == 0:
-        bytes_per_sweep = N * (4 * P + 8)
+        layout = m["layout"]
+        bytes_per_sweep = sweep_bytes(N, P, layout)
         achieved = (bytes_per_sweep * args.steps) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        eq_bytes = sweep_bytes(N, P, "int32")
+        eq_achieved = (eq_bytes * args.steps) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                traffic = json.load(open(tpath)).get(args.workload + ("" if layout == "int32" else "_bits"))
             except Exception:
                 traffic = None
         result = {
@@ -148,7 +162,8 @@ def main():
             "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
                        "sampler": sampler, "K": K, "N": N, "P": P, "batch": batch, "chains": world,
                        "burn_sweeps": args.burn,
-                       "x_layout": "int32 column-major (as R hands it over)",
+                       "x_layout": ("bit planes, ceil(P/32) words per observation, packed once at hand-over"
+                                    if layout == "bits" else "int32 column-major (as R hands it over)"),
                        "allocations_per_s": world * args.steps * N / dt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -157,6 +172,16 @@ def main():
                          "algorithmic_bytes_per_sweep": bytes_per_sweep,
                          "lds_bytes": shape["lds_bytes"], "threads": shape["threads"]},
         }
+        if layout == "bits":
+            # labelled secondary: what an int32-streaming kernel would have to move in this time
+            result["roofline"]["layout"] = "bit planes"
+            result["roofline"]["int32_equivalent"] = {
+                "bytes_per_sweep": eq_bytes, "GBps": eq_achieved,
+                "frac_of_hbm_peak": (eq_achieved / HBM_PEAK_GBS) if eq_achieved else None,
+                "note": "secondary figure, not a roofline fraction: the packed kernel does not move these bytes"}
+            result["roofline"]["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 "
+                                          "layout and is bound by fp64 VALU issue and LDS lookups, not by HBM; the "
+                                          "HBM-bound kernel on the layout R hands over is other_workloads.c5_int32")
         if not args.no_cpu and world == 1:
             from oracle import oracle
             rows = min(args.cpu_rows, N)
@@ -180,9 +205,28 @@ def main():
     # north-star shape.  Reported beside the headline, never instead of it.
     if world == 1 and not args.no_extra and args.workload == "c5" and not (args.n or args.k):
         extra = {}
+        if args.x_layout == "bits":
+            # the kernel that streams the int32 matrix in place: the HBM-roofline measurement proper
+            e = measure("c5", args.steps, args.warmup, args.burn, args.batch, x_layout="int32")
+            bps = sweep_bytes(e["N"], e["P"], "int32")
+            gbps = bps * args.steps / (e["kern_ms"] * 1e-3) / 1e9
+            tr = None
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("c5")
+            except Exception:
+                pass
+            extra["c5_int32"] = {"workload": "c5 with --x-layout int32 (X streamed as R hands it over)",
+                                 "sweeps_per_s": args.steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / args.steps,
+                                 "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / args.steps,
+                                 "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": gbps / HBM_PEAK_GBS, "traffic": tr,
+                                              "algorithmic_bytes_per_sweep": bps}}
+            e["chain"].close()
+            del e
+            torch.cuda.empty_cache()
         for w, steps in (("c2", 200), ("ns", 50)):
-            e = measure(w, steps, 5, args.burn, 0)
-            bps = e["N"] * (4 * e["P"] + 8)
+            e = measure(w, steps, 5, args.burn, 0, x_layout=args.x_layout)
+            bps = sweep_bytes(e["N"], e["P"], e["layout"])
             extra[w] = {"workload": "gibbs_%s K=%d N=%d P=%d" % (e["sampler"], e["K"], e["N"], e["P"]),
                         "sweeps_per_s": steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / steps,
                         "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / steps,

@@ -186,8 +186,10 @@ class Chain:
 
     _CODE = _capi.SAMPLER_CODE
 
+    X_LAYOUT = {"bits": 0, "int32": 1}
+
     def __init__(self, sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, batch=None, seed=0,
-                 device=0):
+                 device=0, x_layout=None):
         self._h = _C.c_void_p()
         self.sampler, self.N, self.P, self.K = sampler, int(N), int(P), int(K)
         self._keep = None
@@ -197,6 +199,13 @@ class Chain:
             _C.c_double(a), _C.c_double(b), _C.c_int64(0 if batch is None else batch),
             _C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _C.c_int(device))
         _capi.check(rc)
+        if x_layout is not None:  # "bits" (default: X packed once into bit planes) or "int32" (as handed over)
+            _capi.check(_capi.lib().bmm_chain_set_x_layout(self._h, _C.c_int(self.X_LAYOUT[x_layout])))
+
+    def x_layout(self):
+        v = _C.c_int(0)
+        _capi.check(_capi.lib().bmm_chain_get_x_layout(self._h, _C.byref(v)))
+        return "int32" if v.value else "bits"
 
     def close(self):
         if self._h:

@@ -17,7 +17,7 @@ NA_INTEGER = -2147483648
 SYMBOLS = [
     "bmm_last_error", "bmm_spec_group_width", "bmm_default_batch", "bmm_collapsed_run", "bmm_dp_run",
     "bmm_sb_run", "bmm_full_run", "bmm_chain_create", "bmm_chain_destroy", "bmm_chain_set_data_host",
-    "bmm_chain_set_data_device", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
+    "bmm_chain_set_data_device", "bmm_chain_set_x_layout", "bmm_chain_get_x_layout", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
     "bmm_chain_sweeps", "bmm_chain_sweeps_counts", "bmm_chain_sweep_probs", "bmm_chain_set_shard", "bmm_chain_shard_resample",
     "bmm_chain_shard_deltas", "bmm_chain_shard_finish", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
     "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",

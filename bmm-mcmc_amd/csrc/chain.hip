@@ -60,40 +60,42 @@ int pick_kt(int cats) {
 int threads_for(int kt) { return kt <= 12 ? kThreadsSmall : (kt <= 20 ? kThreadsMid : kThreadsLarge); }
 
 typedef void (*resample_fn)(ChainParams, ResampleArgs);
-template <int MINUS>
+// BITS: X streamed as bit planes (k_pack_bits) instead of the int32 matrix as handed over
+template <int MINUS, bool BITS>
 resample_fn resample_kernel_m(int kt) {
+    constexpr int SW = BITS ? 16 : kStageWide;
     switch (kt) {
-        case 4: return k_resample<4, kThreadsSmall, MINUS, kStageWide>;
-        case 8: return k_resample<8, kThreadsSmall, MINUS, kStageWide>;
-        case 12: return k_resample<12, kThreadsSmall, MINUS, kStageWide>;
-        case 16: return k_resample<16, kThreadsMid, MINUS, kStageWide>;
-        case 20: return k_resample<20, kThreadsMid, MINUS, kStageWide>;
-        case 24: return k_resample<24, kThreadsLarge, MINUS, 16>;
-        case 28: return k_resample<28, kThreadsLarge, MINUS, 16>;
-        case 32: return k_resample<32, kThreadsLarge, MINUS, 16>;
-        case 40: return k_resample<40, kThreadsLarge, MINUS, 16>;
-        case 48: return k_resample<48, kThreadsLarge, MINUS, 16>;
-        case 56: return k_resample<56, kThreadsLarge, MINUS, 16>;
-        case 64: return k_resample<64, kThreadsLarge, MINUS, 16>;
+        case 4: return k_resample<4, kThreadsSmall, MINUS, SW, BITS>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS, SW, BITS>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS, SW, BITS>;
+        case 16: return k_resample<16, kThreadsMid, MINUS, SW, BITS>;
+        case 20: return k_resample<20, kThreadsMid, MINUS, SW, BITS>;
+        case 24: return k_resample<24, kThreadsLarge, MINUS, 16, BITS>;
+        case 28: return k_resample<28, kThreadsLarge, MINUS, 16, BITS>;
+        case 32: return k_resample<32, kThreadsLarge, MINUS, 16, BITS>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, BITS>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, BITS>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, BITS>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, BITS>;
     }
     return nullptr;
 }
 // 256-thread variants: used when a batch is too small to give every CU a workgroup otherwise
-template <int MINUS>
+template <int MINUS, bool BITS>
 resample_fn resample_kernel_small(int kt) {
     switch (kt) {
-        case 4: return k_resample<4, 256, MINUS, 16>;
-        case 8: return k_resample<8, 256, MINUS, 16>;
-        case 12: return k_resample<12, 256, MINUS, 16>;
-        case 16: return k_resample<16, 256, MINUS, 16>;
-        case 20: return k_resample<20, 256, MINUS, 16>;
-        case 24: return k_resample<24, 256, MINUS, 16>;
-        case 28: return k_resample<28, 256, MINUS, 16>;
-        case 32: return k_resample<32, 256, MINUS, 16>;
-        case 40: return k_resample<40, 256, MINUS, 16>;
-        case 48: return k_resample<48, 256, MINUS, 16>;
-        case 56: return k_resample<56, 256, MINUS, 16>;
-        case 64: return k_resample<64, 256, MINUS, 16>;
+        case 4: return k_resample<4, 256, MINUS, 16, BITS>;
+        case 8: return k_resample<8, 256, MINUS, 16, BITS>;
+        case 12: return k_resample<12, 256, MINUS, 16, BITS>;
+        case 16: return k_resample<16, 256, MINUS, 16, BITS>;
+        case 20: return k_resample<20, 256, MINUS, 16, BITS>;
+        case 24: return k_resample<24, 256, MINUS, 16, BITS>;
+        case 28: return k_resample<28, 256, MINUS, 16, BITS>;
+        case 32: return k_resample<32, 256, MINUS, 16, BITS>;
+        case 40: return k_resample<40, 256, MINUS, 16, BITS>;
+        case 48: return k_resample<48, 256, MINUS, 16, BITS>;
+        case 56: return k_resample<56, 256, MINUS, 16, BITS>;
+        case 64: return k_resample<64, 256, MINUS, 16, BITS>;
     }
     return nullptr;
 }
@@ -110,8 +112,16 @@ resample_fn resample_kernel_dbg(int kt) {
     return nullptr;
 }
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
-resample_fn resample_kernel(int kt, int minus) {
-    return minus == 0 ? resample_kernel_m<0>(kt) : (minus == 1 ? resample_kernel_m<1>(kt) : resample_kernel_m<2>(kt));
+resample_fn resample_kernel(int kt, int minus, bool bits) {
+    if (bits)
+        return minus == 0 ? resample_kernel_m<0, true>(kt)
+                          : (minus == 1 ? resample_kernel_m<1, true>(kt) : resample_kernel_m<2, true>(kt));
+    return minus == 0 ? resample_kernel_m<0, false>(kt)
+                      : (minus == 1 ? resample_kernel_m<1, false>(kt) : resample_kernel_m<2, false>(kt));
+}
+resample_fn resample_kernel_small_of(int kt, int minus, bool bits) {
+    if (bits) return minus == 0 ? resample_kernel_small<0, true>(kt) : resample_kernel_small<1, true>(kt);
+    return minus == 0 ? resample_kernel_small<0, false>(kt) : resample_kernel_small<1, false>(kt);
 }
 
 }  // namespace
@@ -134,6 +144,10 @@ struct bmm_chain {
 
     const int32_t* dX = nullptr;
     int32_t* dX_owned = nullptr;
+    uint32_t* dXb = nullptr;      // bit planes of X (k_pack_bits), what the resident kernels stream by default
+    bool bits = false;
+    int num_cus = 0;
+    bool batch_defaulted = false;
     int32_t* dZ[2] = {nullptr, nullptr};
     int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
     double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
@@ -231,7 +245,7 @@ int chain_alloc(bmm_chain* c) {
 int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t lo, int64_t hi,
                     uint32_t sweep) {
     ResampleArgs a{};
-    a.X = c->dX; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
+    a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
     const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
     int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
@@ -314,6 +328,43 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
     hipLaunchKernelGGL(k_count_sweep_end, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                        c->dDS, c->dAlpha, (uint32_t)j, th_tr, al_tr, nk_tr);
     HIP_TRY(hipGetLastError());
+    return BMM_OK;
+}
+
+// The resident kernel for this chain's shape, workgroup size and X layout (c->bits).
+int pick_kernel(bmm_chain* c) {
+    const ChainParams& p = c->p;
+    const size_t lds_max = 163840;
+    const int minus = explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
+    c->NT = threads_for(p.KT);
+    c->fn = resample_kernel(p.KT, minus, c->bits);
+    if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
+        const int nt = atoi(dbg);
+        resample_fn f = nullptr;
+        if (minus == 1 && !c->bits)
+            f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
+        if (f) { c->fn = f; c->NT = nt; }
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    int per_cu = 0;
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c->fn), c->NT, c->lds_bytes);
+    if (e != hipSuccess) return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e));
+    if (per_cu < 1) per_cu = 1;
+    c->grid_max = per_cu * c->num_cus;
+    // a batch that cannot give every CU a workgroup runs on 256-thread workgroups instead, when the
+    // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
+    const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
+    if (tiles < c->num_cus && c->NT > 256 && c->lds_bytes * 4 <= lds_max && minus != 2 &&
+        !getenv("BMM_DEBUG_THREADS")) {
+        resample_fn f = resample_kernel_small_of(p.KT, minus, c->bits);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        int pc2 = 0;
+        if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(f), 256, c->lds_bytes);
+        if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->grid_max = pc2 * c->num_cus; }
+    }
     return BMM_OK;
 }
 
@@ -432,35 +483,10 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         c->scratch_stride = threads;
         c->grid_max = (int)(threads / 256);
     } else {
-        c->fn = resample_kernel(p.KT, explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2));
-        if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
-            const int nt = atoi(dbg);
-            resample_fn f = nullptr;
-            if (!explicit_params(p.mode) && c->minus_in_lds)
-                f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
-            if (f) { c->fn = f; c->NT = nt; }
-        }
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-        int per_cu = 0;
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c->fn), c->NT, c->lds_bytes);
-        if (e != hipSuccess) { delete c; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
-        if (per_cu < 1) per_cu = 1;
-        c->grid_max = per_cu * prop.multiProcessorCount;
-        // a batch that cannot give every CU a workgroup runs on 256-thread workgroups instead, when the
-        // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
-        const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
-        if (tiles < prop.multiProcessorCount && c->NT > 256 && c->lds_bytes * 4 <= lds_max &&
-            (explicit_params(p.mode) || c->minus_in_lds) &&
-            !getenv("BMM_DEBUG_THREADS")) {
-            resample_fn f = explicit_params(p.mode) ? resample_kernel_small<0>(p.KT) : resample_kernel_small<1>(p.KT);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-            int pc2 = 0;
-            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(f), 256, c->lds_bytes);
-            if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->grid_max = pc2 * prop.multiProcessorCount; }
-        }
+        c->num_cus = prop.multiProcessorCount;
+        c->bits = getenv("BMM_X_LAYOUT_INT32") == nullptr;
+        rc = pick_kernel(c);
+        if (rc) { delete c; return rc; }
     }
     if (batch <= 0 && !explicit_params(sampler)) {
         // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
@@ -491,12 +517,40 @@ void bmm_chain_destroy(bmm_chain* c) {
     }
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
+    void* bufs[] = {c->dX_owned, c->dXb, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
                     c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace, c->dScratch, c->dProbs};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// X -> bit planes, once per chain (the resident kernels' default layout)
+static int pack_bits(bmm_chain* c) {
+    if (!c->bits || c->generic) return BMM_OK;
+    const int W = (c->p.P + 31) / 32;
+    if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * c->p.N * sizeof(uint32_t)));
+    const int64_t nb = (c->p.N + 255) / 256;
+    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, c->stream, c->dX,
+                       c->p.N, c->p.P, c->dXb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMM_OK;
+}
+
+int bmm_chain_set_x_layout(bmm_chain* c, int layout) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (layout != BMM_X_BITPLANES && layout != BMM_X_INT32) return set_err(BMM_E_ARG, "unknown X layout %d", layout);
+    if (c->have_data || c->started) return set_err(BMM_E_STATE, "the X layout is chosen before the data are set");
+    if (c->generic) return BMM_OK;  // the generic path reads the matrix as handed over
+    c->bits = layout == BMM_X_BITPLANES;
+    return pick_kernel(c);
+}
+
+int bmm_chain_get_x_layout(const bmm_chain* c, int* layout) {
+    if (!c || !layout) return set_err(BMM_E_ARG, "null argument");
+    *layout = c->bits && !c->generic ? BMM_X_BITPLANES : BMM_X_INT32;
+    return BMM_OK;
 }
 
 int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
@@ -509,6 +563,8 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dX = c->dX_owned;
     int rc = validate_binary(c);
+    if (rc) return rc;
+    rc = pack_bits(c);
     if (rc) return rc;
     c->have_data = true;
     return BMM_OK;
@@ -526,6 +582,8 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
     c->dX = static_cast<const int32_t*>(dX);
     HIP_TRY(hipSetDevice(c->device));
     int rc = validate_binary(c);
+    if (rc) return rc;
+    rc = pack_bits(c);
     if (rc) return rc;
     c->have_data = true;
     return BMM_OK;

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t*
 // ---------------------------------------------------------------------------------
 struct ResampleArgs {
     const int32_t* X;
+    const uint32_t* Xb;    // bit planes of X: word w of observation i at Xb[w * N + i] (k_pack_bits)
     const int32_t* z_in;   // 0-based labels of the previous sweep, -1 = unassigned
     int32_t* z_out;
     const double* tab;     // table image (TableLayout)
@@ -448,6 +449,33 @@ __device__ __forceinline__ void flush_hist(const int32_t* hist, int K, int P, in
     }
 }
 
+// X as bit planes: word w of observation i (features 32w .. 32w+31, feature d at bit d % 32) at
+// Xb[w * N + i]; bits past P are zero.  X is constant over the whole chain, so the resample kernel
+// streams 4 * ceil(P / 32) bytes per observation and sweep instead of 4 * P.
+__global__ __launch_bounds__(256) void k_pack_bits(const int32_t* __restrict__ X, int64_t N, int P,
+                                                   uint32_t* __restrict__ Xb) {
+    const int W = (P + 31) / 32;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        for (int w = 0; w < W; ++w) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int d = w * 32 + j;
+                if (d < P) v |= ((uint32_t)X[i + (int64_t)d * N] & 1u) << j;
+            }
+            Xb[(int64_t)w * N + i] = v;
+        }
+    }
+}
+// the (up to four) words of observation i; W = ceil(P / 32) is wave-uniform
+__device__ __forceinline__ void load_words(const uint32_t* Xb, int64_t N, int W, int64_t i, uint32_t& w0,
+                                           uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    w0 = Xb[i];
+    w1 = W > 1 ? Xb[N + i] : 0u;
+    w2 = W > 2 ? Xb[2 * N + i] : 0u;
+    w3 = W > 3 ? Xb[3 * N + i] : 0u;
+}
+
 // One pass over X when it is handed over: every cell must be 0 or 1 (the packing above
 // shifts the loaded words without masking).  flag[0] is set when one is not.
 __global__ __launch_bounds__(256) void k_validate_binary(const uint4* __restrict__ X4, int64_t n16,
@@ -518,7 +546,7 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // MINUS says where the own-cluster ("minus self") tables are: 0 none (stick-breaking),
 // 1 in LDS, 2 in global memory.  It is a template parameter because a possible VMEM load in
 // the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
-template <int KT, int NT, int MINUS, int STG>
+template <int KT, int NT, int MINUS, int STG, bool BITS = false>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
     constexpr int GPS = STG / kGroupW;  // lookup groups per stage
     constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
@@ -539,7 +567,9 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const int P = p.P, G = p.G, K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t ntiles = (a.hi - a.lo + NT - 1) / NT;
-    const int nstages = (P + STG - 1) / STG;
+    // BITS: X comes as bit planes, the whole observation is one "stage" of up to four words
+    const int nstages = BITS ? 1 : (P + STG - 1) / STG;
+    const int W = (P + 31) / 32;
 
     int64_t tile = blockIdx.x;
     const bool has_tile = tile < ntiles;
@@ -548,8 +578,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     for (int u = 0; u < STG; ++u) st[u] = 0;
     TilePos pos = tile_pos(a, has_tile ? tile : 0, NT, tid, lane);
     // first loads of the first tile go out before the tables are staged
-    if (has_tile) issue_stage<STG>(pos, p.N, P, 0, st);
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (has_tile) {
+        if (BITS) load_words(a.Xb, p.N, W, pos.ic, b0, b1, b2, b3);
+        else issue_stage<STG>(pos, p.N, P, 0, st);
+    }
     {
         // stage the table image: eight 16-byte loads in flight per lane (one L2 round trip per
         // eight, not per one)
@@ -585,7 +618,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     DIAG(unsigned long long d_nmov = 0, d_ntile = 0; unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
     if (has_tile) {
         // prologue: the rest of the first tile's features, nothing to overlap with yet
-        put_stage<STG>(pack_stage<STG>(P, 0, st), 0, b0, b1, b2, b3);
+        if (!BITS) put_stage<STG>(pack_stage<STG>(P, 0, st), 0, b0, b1, b2, b3);
         // no accumulators are live yet, so 64 loads share one round trip
 #pragma unroll 1
         for (int h0 = 1; h0 < nstages; h0 += 64 / STG) {
@@ -630,10 +663,13 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double acc_own = 0.0;
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
-                if (has_next) issue_stage<STG>(npos, p.N, P, h, st);
+                if (has_next) {
+                    if (BITS) load_words(a.Xb, p.N, W, npos.ic, n0, n1, n2, n3);
+                    else issue_stage<STG>(npos, p.N, P, h, st);
+                }
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
-                const int g_hi = G < (h + 1) * GPS ? G : (h + 1) * GPS;
+                const int g_hi = BITS ? G : (G < (h + 1) * GPS ? G : (h + 1) * GPS);
 #pragma unroll 1
                 for (int g = h * GPS; g < g_hi; ++g) {
                     const unsigned nib = nibble_of(g, b0, b1, b2, b3);
@@ -653,7 +689,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                     if (has_minus) acc_own = acc_own + own;
                 }
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_score += n_ - d_t; d_t = n_; })
-                if (has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
+                if (!BITS && has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_pack += n_ - d_t; d_t = n_; })
             }
             // scores; the observation's own cluster is scored without itself

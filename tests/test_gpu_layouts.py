@@ -1,0 +1,79 @@
+"""The two X layouts of the resident kernel -- bit planes packed once when the matrix is handed
+over (default) and the int32 matrix streamed as R hands it over -- run the same chain: both
+must equal the oracle bit for bit, for every word-boundary shape of P."""
+import numpy as np
+import pytest
+
+import bmm_mcmc_amd as bm
+from util import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _z0(N, K, seed):
+    return np.random.default_rng(seed).integers(1, K + 1, N).astype(np.int32)
+
+
+def _chain_labels(layout, X, K, z0, batch, sweeps=3):
+    N, P = X.shape
+    with bm.Chain("collapsed", N, P, K, batch=batch, seed=21, x_layout=layout) as c:
+        assert c.x_layout() == layout
+        c.set_data(X)
+        c.set_initial_labels(z0)
+        c.sweeps(sweeps)
+        c.sync()
+        return c.labels(), c.counts()
+
+
+@pytest.mark.parametrize("P", [1, 4, 31, 32, 33, 63, 64, 65, 96, 97, 100, 127, 128])
+def test_bit_planes_and_int32_run_the_same_chain(oracle, P):
+    N, K, batch = 3000, 5, 700
+    X, _, _, _ = synth(N, P, 3, 100 + P)
+    z0 = _z0(N, K, 2)
+    zb, (nb, sb) = _chain_labels("bits", X, K, z0, batch)
+    zi, (ni, si) = _chain_labels("int32", X, K, z0, batch)
+    assert np.array_equal(zb, zi) and np.array_equal(nb, ni) and np.array_equal(sb, si)
+    want = oracle.collapsed(X, z0, 4, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=21, batch=batch)
+    assert np.array_equal(zb, want["z"][3])
+    assert np.array_equal(sb, np.stack([X[zb == k + 1].sum(axis=0) for k in range(K)]))
+
+
+@pytest.mark.parametrize("env", [None, "1"])
+def test_run_entry_points_under_both_layouts(oracle, monkeypatch, env):
+    # the *_run entry points have no layout argument: BMM_X_LAYOUT_INT32 switches them
+    if env is None:
+        monkeypatch.delenv("BMM_X_LAYOUT_INT32", raising=False)
+    else:
+        monkeypatch.setenv("BMM_X_LAYOUT_INT32", env)
+    X, _, _, _ = synth(4000, 50, 4, 3)
+    z0 = _z0(4000, 20, 9)
+    got = bm.gibbs_collapsed(X, 6, 20, burnin=0, seed=5, batch=512, initial_K=z0)
+    want = oracle.collapsed(X, z0, 6, 20, 0.0, 0.5, 0.5, 1, 1, 0, seed=5, batch=512)
+    for k in ("z", "theta", "alpha"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    got = bm.gibbs_dp(X, 6, burnin=0, maxK=12, seed=5, batch=256)
+    want = oracle.dp(X, 6, 0.0, 0.5, 0.5, 1, 1, 0, 12, seed=5, batch=256)
+    for k in ("z", "theta", "alpha"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    rng = np.random.default_rng(1)
+    pi0 = rng.dirichlet(np.ones(10))
+    th0 = rng.random((10, 50))
+    got = bm.gibbs_stickbreaking(X, 5, 10, burnin=0, seed=8, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 5, 10, 0.0, 0.5, 0.5, 1, 1, 0, seed=8)
+    for k in ("z", "theta", "alpha", "pi"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+def test_layout_is_fixed_once_the_data_are_set():
+    X, _, _, _ = synth(500, 8, 2, 1)
+    with bm.Chain("collapsed", 500, 8, 2, seed=1) as c:
+        assert c.x_layout() == "bits"
+        c.set_data(X)
+        with pytest.raises(bm.BmmError):
+            _capi_set(c, 1)
+
+
+def _capi_set(c, layout):
+    import ctypes
+    from bmm_mcmc_amd import _capi
+    _capi.check(_capi.lib().bmm_chain_set_x_layout(c._h, ctypes.c_int(layout)))

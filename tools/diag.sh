@@ -1,9 +1,18 @@
 #!/bin/bash
-# Diagnostic-build run on the GPU box: swaps in the -DBMM_DIAG library for one bench run
-# and prints the per-phase cycle shares each chain reports on destroy.  Never timed.
+# Diagnostic-build run: `tools/diag.sh build` (in the build container) compiles the -DBMM_DIAG
+# library next to the product one; `tools/diag.sh [bench.py flags]` (on the GPU box) swaps it in
+# for one bench run and prints the per-phase tick shares each chain reports on destroy.
+# Never timed, never shipped.
 set -e
+cd "$(dirname "$0")/.."
 L=bmm-mcmc_amd/lib
+if [ "$1" = build ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DBMM_DIAG \
+    -Wl,-rpath,/opt/rocm/lib -o $L/libbmmmcmc_hip_diag.so bmm-mcmc_amd/csrc/chain.hip
+  exit 0
+fi
+[ -f $L/libbmmmcmc_hip_diag.so ] || { echo "run tools/diag.sh build first" >&2; exit 1; }
 cp $L/libbmmmcmc_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so $L/libbmmmcmc_hip.so' EXIT
 cp $L/libbmmmcmc_hip_diag.so $L/libbmmmcmc_hip.so
-python bench.py --no-cpu "$@" 2>&1 >/dev/null | grep "bmm diag" || true
-cp /tmp/keep.so $L/libbmmmcmc_hip.so
+python bench.py --no-cpu --no-extra "$@" 2>&1 >/dev/null | grep "bmm diag" || true
