@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--x-layout", default="bits", choices=["bits", "int32"],
                     help="what the resample kernel streams: bit planes packed once at hand-over (default) "
                          "or the int32 matrix as R hands it over")
+    ap.add_argument("--event-stride", type=int, default=4, help="time the resample launches of every n-th sweep")
+    ap.add_argument("--no-events", action="store_true",
+                    help="debug: no HIP events around the resample launches (roofline is then null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / north-star side measurements")
     ap.add_argument("--shard", action="store_true",
@@ -108,7 +111,9 @@ def main():
         ch.sweeps(burn)
         ch.sweeps(warmup)
         ch.sync()
-        ch.profile(True)
+        # HIP events around the resample launches of every 4th timed sweep: the per-launch average
+        # is what the roofline needs, and 16 event records per sweep would cost ~7 % of the sweep
+        ch.profile(0 if args.no_events else args.event_stride)
         barrier()
         t0 = time.perf_counter()
         ch.sweeps(steps)
@@ -117,8 +122,13 @@ def main():
         t1 = time.perf_counter()
         kern_ms, kern_n = ch.profile_read()
         ch.profile(False)
+        # launches per sweep are structural: one per batch (one in all for the explicit-parameter samplers)
+        lps = 1 if sampler in ("stickbreaking", "full") else -(-N // ch.batch)
+        per_launch = (kern_ms / kern_n) if kern_n else 0.0
+        kern_ms = multi.max_over_ranks(per_launch * lps * steps)  # resample-kernel ms over the timed sweeps
+        kern_n = lps * steps
         m = {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
-             "dt": multi.max_over_ranks(t1 - t0), "kern_ms": multi.max_over_ranks(kern_ms), "kern_n": kern_n,
+             "dt": multi.max_over_ranks(t1 - t0), "kern_ms": kern_ms, "kern_n": kern_n,
              "X": X, "chain": ch, "layout": ch.x_layout()}
         return m
 

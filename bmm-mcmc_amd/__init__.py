@@ -314,8 +314,9 @@ class Chain:
         _capi.check(_capi.lib().bmm_chain_get_params(self._h, _capi.vp(pi), _capi.vp(theta)))
         return pi, theta
 
-    def profile(self, enable=True):
-        _capi.check(_capi.lib().bmm_chain_profile(self._h, _C.c_int(1 if enable else 0)))
+    def profile(self, every=1):
+        """Time the resample launches of every `every`-th sweep with HIP events (0/False: off)."""
+        _capi.check(_capi.lib().bmm_chain_profile(self._h, _C.c_int(int(every))))
 
     def profile_read(self):
         ms, n = _C.c_double(0.0), _C.c_int64(0)

@@ -57,7 +57,11 @@ int pick_kt(int cats) {
         if (kt >= cats) return kt;
     return -1;
 }
-int threads_for(int kt) { return kt <= 12 ? kThreadsSmall : (kt <= 20 ? kThreadsMid : kThreadsLarge); }
+// the bit-plane kernel holds no feature loads in flight, which frees 20-odd VGPRs: one size up
+int threads_for(int kt, bool bits) {
+    if (bits) return kt <= 20 ? kThreadsSmall : (kt <= 32 ? kThreadsMid : kThreadsLarge);
+    return kt <= 12 ? kThreadsSmall : (kt <= 20 ? kThreadsMid : kThreadsLarge);
+}
 
 typedef void (*resample_fn)(ChainParams, ResampleArgs);
 // BITS: X streamed as bit planes (k_pack_bits) instead of the int32 matrix as handed over
@@ -68,11 +72,11 @@ resample_fn resample_kernel_m(int kt) {
         case 4: return k_resample<4, kThreadsSmall, MINUS, SW, BITS>;
         case 8: return k_resample<8, kThreadsSmall, MINUS, SW, BITS>;
         case 12: return k_resample<12, kThreadsSmall, MINUS, SW, BITS>;
-        case 16: return k_resample<16, kThreadsMid, MINUS, SW, BITS>;
-        case 20: return k_resample<20, kThreadsMid, MINUS, SW, BITS>;
-        case 24: return k_resample<24, kThreadsLarge, MINUS, 16, BITS>;
-        case 28: return k_resample<28, kThreadsLarge, MINUS, 16, BITS>;
-        case 32: return k_resample<32, kThreadsLarge, MINUS, 16, BITS>;
+        case 16: return k_resample<16, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS>;
+        case 20: return k_resample<20, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS>;
+        case 24: return k_resample<24, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
+        case 28: return k_resample<28, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
+        case 32: return k_resample<32, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
         case 40: return k_resample<40, kThreadsLarge, MINUS, 16, BITS>;
         case 48: return k_resample<48, kThreadsLarge, MINUS, 16, BITS>;
         case 56: return k_resample<56, kThreadsLarge, MINUS, 16, BITS>;
@@ -100,14 +104,15 @@ resample_fn resample_kernel_small(int kt) {
     return nullptr;
 }
 // experiment hook (BMM_DEBUG_THREADS=768|512): the KT <= 20 kernels at a smaller workgroup
-template <int NT>
+template <int NT, bool BITS>
 resample_fn resample_kernel_dbg(int kt) {
+    constexpr int SW = BITS ? 16 : kStageWide;
     switch (kt) {
-        case 4: return k_resample<4, NT, 1, kStageWide>;
-        case 8: return k_resample<8, NT, 1, kStageWide>;
-        case 12: return k_resample<12, NT, 1, kStageWide>;
-        case 16: return k_resample<16, NT, 1, kStageWide>;
-        case 20: return k_resample<20, NT, 1, kStageWide>;
+        case 4: return k_resample<4, NT, 1, SW, BITS>;
+        case 8: return k_resample<8, NT, 1, SW, BITS>;
+        case 12: return k_resample<12, NT, 1, SW, BITS>;
+        case 16: return k_resample<16, NT, 1, SW, BITS>;
+        case 20: return k_resample<20, NT, 1, SW, BITS>;
     }
     return nullptr;
 }
@@ -148,6 +153,7 @@ struct bmm_chain {
     bool bits = false;
     int num_cus = 0;
     bool batch_defaulted = false;
+    int64_t batch_unrounded = 0;
     int32_t* dZ[2] = {nullptr, nullptr};
     int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
     double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
@@ -162,7 +168,7 @@ struct bmm_chain {
     int32_t* dNkTrace = nullptr;  // [n][K] cluster sizes per sweep of the current sweeps_counts call
     int nk_trace_base = 0;        // sweep index of its row 0
     unsigned long long* dDiag = nullptr;
-    bool prof = false;
+    int prof = 0;             // > 0: HIP events around the resample launches of every prof-th sweep
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double prof_ms = 0.0;
@@ -257,7 +263,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
         a.probs = c->probs_sweep ? c->dProbs : nullptr;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->prof) {
+    if (c->prof > 0 && sweep % (uint32_t)c->prof == 0) {
         if (c->ev_used + 2 > c->ev.size()) {
             hipEvent_t a0, a1;
             HIP_TRY(hipEventCreate(&a0));
@@ -336,13 +342,16 @@ int pick_kernel(bmm_chain* c) {
     const ChainParams& p = c->p;
     const size_t lds_max = 163840;
     const int minus = explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
-    c->NT = threads_for(p.KT);
+    c->NT = threads_for(p.KT, c->bits);
     c->fn = resample_kernel(p.KT, minus, c->bits);
     if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
         resample_fn f = nullptr;
         if (minus == 1 && !c->bits)
-            f = nt == 768 ? resample_kernel_dbg<768>(p.KT) : (nt == 512 ? resample_kernel_dbg<512>(p.KT) : nullptr);
+            f = nt == 768 ? resample_kernel_dbg<768, false>(p.KT) : (nt == 512 ? resample_kernel_dbg<512, false>(p.KT) : nullptr);
+        if (minus == 1 && c->bits)
+            f = nt == 1024 ? resample_kernel_dbg<1024, true>(p.KT)
+                           : (nt == 768 ? resample_kernel_dbg<768, true>(p.KT) : (nt == 512 ? resample_kernel_dbg<512, true>(p.KT) : nullptr));
         if (f) { c->fn = f; c->NT = nt; }
     }
     hipError_t e = hipSetDevice(c->device);
@@ -366,6 +375,15 @@ int pick_kernel(bmm_chain* c) {
         if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->grid_max = pc2 * c->num_cus; }
     }
     return BMM_OK;
+}
+
+// a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
+void round_default_batch(bmm_chain* c) {
+    if (!c->batch_defaulted) return;
+    const int64_t round = (int64_t)c->grid_max * c->NT;
+    c->batch = c->batch_unrounded;
+    if (c->batch > round) c->batch = (c->batch + round - 1) / round * round;
+    if (c->batch > c->p.N) c->batch = c->p.N;
 }
 
 // things that must be in place before the first sweep
@@ -462,7 +480,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
     c->generic = p.KT < 0 || P > kMaxP || getenv("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {
-        c->NT = threads_for(p.KT);
+        c->NT = threads_for(p.KT, false);
         c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
         if (c->lds_bytes > lds_max && !explicit_params(p.mode)) {  // second tier: own-cluster tables stay in L2
             c->minus_in_lds = 0;
@@ -488,12 +506,9 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         rc = pick_kernel(c);
         if (rc) { delete c; return rc; }
     }
-    if (batch <= 0 && !explicit_params(sampler)) {
-        // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
-        const int64_t round = (int64_t)c->grid_max * c->NT;
-        if (c->batch > round) c->batch = (c->batch + round - 1) / round * round;
-        if (c->batch > N) c->batch = N;
-    }
+    c->batch_defaulted = batch <= 0 && !explicit_params(sampler);
+    c->batch_unrounded = c->batch;
+    round_default_batch(c);
     rc = chain_alloc(c);
     if (rc) { bmm_chain_destroy(c); return rc; }
     *out = c;
@@ -544,7 +559,10 @@ int bmm_chain_set_x_layout(bmm_chain* c, int layout) {
     if (c->have_data || c->started) return set_err(BMM_E_STATE, "the X layout is chosen before the data are set");
     if (c->generic) return BMM_OK;  // the generic path reads the matrix as handed over
     c->bits = layout == BMM_X_BITPLANES;
-    return pick_kernel(c);
+    int rc = pick_kernel(c);
+    if (rc) return rc;
+    round_default_batch(c);
+    return BMM_OK;
 }
 
 int bmm_chain_get_x_layout(const bmm_chain* c, int* layout) {
@@ -787,7 +805,7 @@ int bmm_chain_profile(bmm_chain* c, int enable) {
     if (!c) return set_err(BMM_E_ARG, "null chain");
     int rc = bmm_chain_sync(c);
     if (rc) return rc;
-    c->prof = enable != 0;
+    c->prof = enable > 0 ? enable : 0;
     c->prof_ms = 0.0;
     c->prof_n = 0;
     return BMM_OK;
