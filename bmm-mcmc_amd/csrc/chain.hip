@@ -103,17 +103,34 @@ resample_fn resample_kernel_small(int kt) {
     }
     return nullptr;
 }
-// experiment hook (BMM_DEBUG_THREADS=768|512): the KT <= 20 kernels at a smaller workgroup
-template <int NT, bool BITS>
-resample_fn resample_kernel_dbg(int kt) {
+// the same kernels at a chosen workgroup size (up to 32 categories): used when a batch is too
+// small to give every CU one of the default-sized workgroups, and by BMM_DEBUG_THREADS
+template <int NT, int MINUS, bool BITS>
+resample_fn resample_kernel_nt(int kt) {
     constexpr int SW = BITS ? 16 : kStageWide;
     switch (kt) {
-        case 4: return k_resample<4, NT, 1, SW, BITS>;
-        case 8: return k_resample<8, NT, 1, SW, BITS>;
-        case 12: return k_resample<12, NT, 1, SW, BITS>;
-        case 16: return k_resample<16, NT, 1, SW, BITS>;
-        case 20: return k_resample<20, NT, 1, SW, BITS>;
+        case 4: return k_resample<4, NT, MINUS, SW, BITS>;
+        case 8: return k_resample<8, NT, MINUS, SW, BITS>;
+        case 12: return k_resample<12, NT, MINUS, SW, BITS>;
+        case 16: return k_resample<16, NT, MINUS, SW, BITS>;
+        case 20: return k_resample<20, NT, MINUS, SW, BITS>;
+        case 24: return k_resample<24, NT, MINUS, 16, BITS>;
+        case 28: return k_resample<28, NT, MINUS, 16, BITS>;
+        case 32: return k_resample<32, NT, MINUS, 16, BITS>;
     }
+    return nullptr;
+}
+resample_fn resample_kernel_at(int kt, int nt, int minus, bool bits) {
+    if (minus == 2) return nullptr;
+    if (bits) {
+        if (nt == 768) return minus ? resample_kernel_nt<768, 1, true>(kt) : resample_kernel_nt<768, 0, true>(kt);
+        if (nt == 512) return minus ? resample_kernel_nt<512, 1, true>(kt) : resample_kernel_nt<512, 0, true>(kt);
+        if (nt == 1024 && kt <= 20) return minus ? resample_kernel_nt<1024, 1, true>(kt) : resample_kernel_nt<1024, 0, true>(kt);
+        return nullptr;
+    }
+    if (kt > 20 || minus != 1) return nullptr;
+    if (nt == 768) return resample_kernel_nt<768, 1, false>(kt);
+    if (nt == 512) return resample_kernel_nt<512, 1, false>(kt);
     return nullptr;
 }
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
@@ -346,13 +363,13 @@ int pick_kernel(bmm_chain* c) {
     c->fn = resample_kernel(p.KT, minus, c->bits);
     if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
-        resample_fn f = nullptr;
-        if (minus == 1 && !c->bits)
-            f = nt == 768 ? resample_kernel_dbg<768, false>(p.KT) : (nt == 512 ? resample_kernel_dbg<512, false>(p.KT) : nullptr);
-        if (minus == 1 && c->bits)
-            f = nt == 1024 ? resample_kernel_dbg<1024, true>(p.KT)
-                           : (nt == 768 ? resample_kernel_dbg<768, true>(p.KT) : (nt == 512 ? resample_kernel_dbg<512, true>(p.KT) : nullptr));
-        if (f) { c->fn = f; c->NT = nt; }
+        if (resample_fn f = resample_kernel_at(p.KT, nt, minus, c->bits)) { c->fn = f; c->NT = nt; }
+    } else if (c->bits) {
+        // a batch that cannot give every CU a workgroup of the default size gets smaller ones
+        for (int nt : {768, 512}) {
+            if ((c->batch + c->NT - 1) / c->NT >= c->num_cus || nt >= c->NT) continue;
+            if (resample_fn f = resample_kernel_at(p.KT, nt, minus, true)) { c->fn = f; c->NT = nt; }
+        }
     }
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess)

@@ -567,9 +567,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const int P = p.P, G = p.G, K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t ntiles = (a.hi - a.lo + NT - 1) / NT;
-    // BITS: X comes as bit planes, the whole observation is one "stage" of up to four words
-    const int nstages = BITS ? 1 : (P + STG - 1) / STG;
+    // BITS: X comes as bit planes; a "stage" is then one 32-bit word = eight lookup groups, all
+    // (up to four) words of the next tile being loaded with the first stage
     const int W = (P + 31) / 32;
+    const int nstages = BITS ? W : (P + STG - 1) / STG;
+    constexpr int GPSX = BITS ? 8 : GPS;
 
     int64_t tile = blockIdx.x;
     const bool has_tile = tile < ntiles;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         if (!BITS) put_stage<STG>(pack_stage<STG>(P, 0, st), 0, b0, b1, b2, b3);
         // no accumulators are live yet, so 64 loads share one round trip
 #pragma unroll 1
-        for (int h0 = 1; h0 < nstages; h0 += 64 / STG) {
+        for (int h0 = 1; !BITS && h0 < nstages; h0 += 64 / STG) {
             uint32_t s0[STG], s1[STG], s2[STG], s3[STG];
 #pragma unroll
             for (int u = 0; u < STG; ++u) { s0[u] = 0; s1[u] = 0; s2[u] = 0; s3[u] = 0; }
@@ -664,15 +666,16 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
                 if (has_next) {
-                    if (BITS) load_words(a.Xb, p.N, W, npos.ic, n0, n1, n2, n3);
+                    if (BITS) { if (h == 0) load_words(a.Xb, p.N, W, npos.ic, n0, n1, n2, n3); }
                     else issue_stage<STG>(npos, p.N, P, h, st);
                 }
+                const uint32_t cur = h == 0 ? b0 : (h == 1 ? b1 : (h == 2 ? b2 : b3));  // BITS: this stage's word
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
-                const int g_hi = BITS ? G : (G < (h + 1) * GPS ? G : (h + 1) * GPS);
+                const int g_hi = G < (h + 1) * GPSX ? G : (h + 1) * GPSX;
 #pragma unroll 1
-                for (int g = h * GPS; g < g_hi; ++g) {
-                    const unsigned nib = nibble_of(g, b0, b1, b2, b3);
+                for (int g = h * GPSX; g < g_hi; ++g) {
+                    const unsigned nib = BITS ? (cur >> ((g & 7) * 4)) & 15u : nibble_of(g, b0, b1, b2, b3);
                     const volatile lds_f64* row = Tp + ((size_t)g * KT * kGroupM + nib);
                     double own = 0.0;
                     if (MINUS == 1) own = TmL[((size_t)g * KT + zoc) * kGroupM + nib];
