@@ -302,7 +302,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
 }
 
 int launch_count_tables(bmm_chain* c) {
-    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(256), 0, c->stream, c->p, c->dNk, c->dS,
+    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(320), 0, c->stream, c->p, c->dNk, c->dS,
                        c->dDNk, c->dDS, c->dAlpha, c->dTab);
     HIP_TRY(hipGetLastError());
     return BMM_OK;
@@ -348,7 +348,7 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
         if (rc) return rc;
         lo = hi;
     }
-    hipLaunchKernelGGL(k_count_sweep_end, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
+    hipLaunchKernelGGL(k_count_sweep_end, dim3(1), dim3(1024), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                        c->dDS, c->dAlpha, (uint32_t)j, th_tr, al_tr, nk_tr);
     HIP_TRY(hipGetLastError());
     return BMM_OK;

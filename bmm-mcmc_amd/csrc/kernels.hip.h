@@ -85,64 +85,32 @@ __device__ __forceinline__ void write_group_tables(const double* e1, const doubl
     }
 }
 
-__global__ __launch_bounds__(256) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
+__global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
                                                       int32_t* __restrict__ S,
                                                       int32_t* __restrict__ dNk,
                                                       int32_t* __restrict__ dS,
                                                       const double* __restrict__ alpha_ptr,
                                                       double* __restrict__ tab) {
     __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP];
-    __shared__ int64_t n_sh;
     const int k = blockIdx.x;
     const TableLayout L{p.G, p.KT, 1};
     const int P = p.P;
-    const double alpha = *alpha_ptr;
-    int64_t n = 0;
     const bool is_label = k < p.K;
-    if (is_label) {
-        if (threadIdx.x == 0) {
-            const int32_t v = Nk[k] + dNk[k];
-            Nk[k] = v; dNk[k] = 0; n_sh = v;
-        }
-        __syncthreads();
-        n = n_sh;
-    }
+    // 320 threads: the first 128 compute the full-statistics terms of feature d, the next 128 its
+    // "minus self" terms (two logs each instead of four in sequence), the fifth wave the per-cluster
+    // constants (three more logs) beside them
+    const int half = threadIdx.x >> 7, dl = threadIdx.x < 256 ? (threadIdx.x & 127) : kMaxP;
+    // every load this workgroup depends on goes out first, in one round trip: the cluster size
+    // (read by every thread: a broadcast, no LDS hand-over), the concentration, the first chunk of counts
+    int32_t n_old = 0, n_dl = 0, s_old = 0, s_dl = 0;
+    if (is_label) { n_old = Nk[k]; n_dl = dNk[k]; }
+    if (is_label && dl < P) { s_old = S[(size_t)k * P + dl]; s_dl = dS[(size_t)k * P + dl]; }
+    const double alpha = *alpha_ptr;
+    const int64_t n = (int64_t)n_old + n_dl;
     const double bg = p.beta + p.gamma;
     const double den_p = n > 0 ? log_(bg + (double)n) : 0.0;
     const double den_m = n > 1 ? log_(bg + (double)(n - 1)) : 0.0;
-    // 256 threads: the lower half computes the full-statistics terms of feature d, the upper half
-    // its "minus self" terms (two logs each instead of four in sequence)
-    const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
-    for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
-        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
-        if (dl < pc) {
-            const int d = c0 + dl;
-            double t1 = 0.0, t0 = 0.0;
-            if (is_label) {
-                const int32_t s = S[(size_t)k * P + d] + dS[(size_t)k * P + d];
-                if (half == 0) {
-                    if (n > 0) {
-                        t1 = term_x1(p.beta, s, den_p);
-                        t0 = term_x0(p.gamma, n, s, den_p);
-                    }
-                } else if (n > 1) {
-                    t1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
-                    t0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
-                }
-            }
-            if (half == 0) { e1[dl] = t1; e0[dl] = t0; } else { m1[dl] = t1; m0[dl] = t0; }
-        }
-        __syncthreads();  // both halves have read S + dS before either is rewritten
-        if (half == 0 && dl < pc && is_label) {
-            const int d = c0 + dl;
-            S[(size_t)k * P + d] += dS[(size_t)k * P + d];
-            dS[(size_t)k * P + d] = 0;
-        }
-        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
-        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 256) {
         double cp = neg_inf(), cm = neg_inf();
         const double ldN = log_((double)(p.Ntot - 1) + alpha);
         if (is_label) {
@@ -160,6 +128,40 @@ __global__ __launch_bounds__(256) void k_count_tables(ChainParams p, int32_t* __
         tab[L.cp() + k] = cp;
         tab[L.cm() + k] = cm;
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
+    }
+    for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
+        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
+        int32_t s = 0;
+        if (dl < pc) {
+            const int d = c0 + dl;
+            double t1 = 0.0, t0 = 0.0;
+            if (is_label) {
+                s = c0 == 0 ? s_old + s_dl : S[(size_t)k * P + d] + dS[(size_t)k * P + d];
+                if (half == 0) {
+                    if (n > 0) {
+                        t1 = term_x1(p.beta, s, den_p);
+                        t0 = term_x0(p.gamma, n, s, den_p);
+                    }
+                } else if (n > 1) {
+                    t1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
+                    t0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
+                }
+            }
+            if (half == 0) { e1[dl] = t1; e0[dl] = t0; } else { m1[dl] = t1; m0[dl] = t0; }
+        }
+        __syncthreads();  // both halves have read S + dS before either is rewritten
+        if (half == 0 && dl < pc && is_label) {
+            const int d = c0 + dl;
+            S[(size_t)k * P + d] = s;
+            dS[(size_t)k * P + d] = 0;
+        }
+        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
+        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
+        __syncthreads();
+    }
+    if (is_label && threadIdx.x == 0) {  // every thread read the old pair before the barriers above
+        Nk[k] = (int32_t)n;
+        dNk[k] = 0;
     }
     if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
 }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
 
 // Counting samplers, end of sweep: fold what the last batch left, theta-hat = S/Nk
 // (NaN for an empty cluster in the finite sampler, 0 for an unused DP label), alpha.
-__global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t* __restrict__ Nk,
+__global__ __launch_bounds__(1024) void k_count_sweep_end(ChainParams p, int32_t* __restrict__ Nk,
                                                          int32_t* __restrict__ S,
                                                          int32_t* __restrict__ dNk,
                                                          int32_t* __restrict__ dS,
@@ -296,7 +298,10 @@ __global__ __launch_bounds__(256) void k_count_sweep_end(ChainParams p, int32_t*
         if (nk_trace) nk_trace[k] = n;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
+    // the first wave draws alpha (below) while the others fold the counts
+    const int nfold = blockDim.x > 64 ? blockDim.x - 64 : blockDim.x;
+    const int t0 = blockDim.x > 64 ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+    for (int idx = t0 < 0 ? K * P : t0; idx < K * P; idx += nfold) {
         const int k = idx / P, d = idx % P;
         const int32_t s = S[idx] + dS[idx];
         S[idx] = s; dS[idx] = 0;
