@@ -133,6 +133,18 @@ resample_fn resample_kernel_at(int kt, int nt, int minus, bool bits) {
     if (nt == 512) return resample_kernel_nt<512, 1, false>(kt);
     return nullptr;
 }
+// more than 32 accumulators on bit planes: two lanes per observation (SPLIT = 2 in kernels.hip.h)
+constexpr int kThreadsSplit = 768;
+template <int MINUS>
+resample_fn resample_kernel_split(int kt) {
+    switch (kt) {
+        case 40: return k_resample<40, kThreadsSplit, MINUS, 16, true, 2>;
+        case 48: return k_resample<48, kThreadsSplit, MINUS, 16, true, 2>;
+        case 56: return k_resample<56, kThreadsSplit, MINUS, 16, true, 2>;
+        case 64: return k_resample<64, kThreadsSplit, MINUS, 16, true, 2>;
+    }
+    return nullptr;
+}
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
 resample_fn resample_kernel(int kt, int minus, bool bits) {
     if (bits)
@@ -155,6 +167,7 @@ struct bmm_chain {
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
+    int OT = 0;  // observations per tile (= NT, or NT / 2 for the two-lanes-per-observation kernels)
     bool sharded = false, shard_open = false;  // one chain over several ranks (explicit-parameter samplers)
     bool generic = false;         // shape beyond the resident kernel: tables from global memory
     double* dScratch = nullptr;   // generic path: per-thread score columns
@@ -270,7 +283,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     ResampleArgs a{};
     a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
-    const int64_t ntiles = (hi - lo + c->NT - 1) / c->NT;
+    const int64_t ntiles = (hi - lo + c->OT - 1) / c->OT;
     int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
     const bool use_generic = c->generic || c->probs_sweep;
     if (use_generic) {
@@ -361,10 +374,16 @@ int pick_kernel(bmm_chain* c) {
     const int minus = explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
     c->NT = threads_for(p.KT, c->bits);
     c->fn = resample_kernel(p.KT, minus, c->bits);
+    int split = 1;
+    if (c->bits && p.KT > 32 && minus != 2 && !getenv("BMM_DEBUG_NOSPLIT")) {
+        c->fn = minus ? resample_kernel_split<1>(p.KT) : resample_kernel_split<0>(p.KT);
+        c->NT = kThreadsSplit;
+        split = 2;
+    }
     if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
         if (resample_fn f = resample_kernel_at(p.KT, nt, minus, c->bits)) { c->fn = f; c->NT = nt; }
-    } else if (c->bits) {
+    } else if (c->bits && split == 1) {
         // a batch that cannot give every CU a workgroup of the default size gets smaller ones
         for (int nt : {768, 512}) {
             if ((c->batch + c->NT - 1) / c->NT >= c->num_cus || nt >= c->NT) continue;
@@ -382,14 +401,15 @@ int pick_kernel(bmm_chain* c) {
     c->grid_max = per_cu * c->num_cus;
     // a batch that cannot give every CU a workgroup runs on 256-thread workgroups instead, when the
     // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
+    c->OT = c->NT / split;
     const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
-    if (tiles < c->num_cus && c->NT > 256 && c->lds_bytes * 4 <= lds_max && minus != 2 &&
+    if (split == 1 && tiles < c->num_cus && c->NT > 256 && c->lds_bytes * 4 <= lds_max && minus != 2 &&
         !getenv("BMM_DEBUG_THREADS")) {
         resample_fn f = resample_kernel_small_of(p.KT, minus, c->bits);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
         int pc2 = 0;
         if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(f), 256, c->lds_bytes);
-        if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->grid_max = pc2 * c->num_cus; }
+        if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->OT = 256; c->grid_max = pc2 * c->num_cus; }
     }
     return BMM_OK;
 }
@@ -397,7 +417,7 @@ int pick_kernel(bmm_chain* c) {
 // a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
 void round_default_batch(bmm_chain* c) {
     if (!c->batch_defaulted) return;
-    const int64_t round = (int64_t)c->grid_max * c->NT;
+    const int64_t round = (int64_t)c->grid_max * c->OT;
     c->batch = c->batch_unrounded;
     if (c->batch > round) c->batch = (c->batch + round - 1) / round * round;
     if (c->batch > c->p.N) c->batch = c->p.N;
@@ -498,6 +518,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     c->generic = p.KT < 0 || P > kMaxP || getenv("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {
         c->NT = threads_for(p.KT, false);
+        c->OT = c->NT;
         c->lds_bytes = (size_t)layout_of(c).doubles() * sizeof(double) + hist_bytes;
         if (c->lds_bytes > lds_max && !explicit_params(p.mode)) {  // second tier: own-cluster tables stay in L2
             c->minus_in_lds = 0;
@@ -509,6 +530,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         // any shape: tables gathered from global memory, scores in a scratch column per thread
         p.KT = (p.Kc + 3) / 4 * 4;
         c->NT = 256;
+        c->OT = 256;
         c->lds_bytes = 0;
         c->minus_in_lds = 0;
         int64_t threads = (int64_t)256 * 1024;

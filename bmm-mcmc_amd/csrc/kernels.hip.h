@@ -551,11 +551,19 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // MINUS says where the own-cluster ("minus self") tables are: 0 none (stick-breaking),
 // 1 in LDS, 2 in global memory.  It is a template parameter because a possible VMEM load in
 // the lookup loop makes the compiler wait vmcnt(0) there, which would drain the HBM prefetch.
-template <int KT, int NT, int MINUS, int STG, bool BITS = false>
+// SPLIT = 2 (bit planes only, for more than 32 accumulators): an observation is shared by lanes l
+// and l + 32 of a wave, each scoring half of the categories -- half the accumulator registers per
+// lane, so twice the waves per SIMD; the halves meet through three lane exchanges (maximum, running
+// sum, count), all in the order the one-lane form uses, so the draw is bit-identical.
+template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    static_assert(SPLIT == 1 || (SPLIT == 2 && BITS && MINUS != 2 && KT % 2 == 0), "split form");
     constexpr int GPS = STG / kGroupW;  // lookup groups per stage
-    constexpr int CH = KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4);  // lookups issued together
-    static_assert(KT % CH == 0, "chunking");
+    constexpr int KH = KT / SPLIT;      // accumulators per lane
+    constexpr int OT = NT / SPLIT;      // observations per tile
+    constexpr int CH = SPLIT == 2 ? (KH <= 20 ? KH : KH / 2)
+                                  : (KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4));  // lookups issued together
+    static_assert(KH % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool has_minus = MINUS != 0;
     const TableLayout L{p.G, KT, has_minus ? 1 : 0};
@@ -571,7 +579,18 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     int32_t* const hist = reinterpret_cast<int32_t*>(lds + lds_doubles);  // [K*P] then [K]
     const int P = p.P, G = p.G, K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t ntiles = (a.hi - a.lo + NT - 1) / NT;
+    const int half = SPLIT == 2 ? lane >> 5 : 0;  // which half of the categories this lane scores
+    const int kb = half * KH;
+    const int64_t ntiles = (a.hi - a.lo + OT - 1) / OT;
+    auto tpos = [&](int64_t t) -> TilePos {
+        if (SPLIT == 1) return tile_pos(a, t, NT, tid, lane);
+        TilePos q;  // lanes l and l + 32 of a wave stand on the same observation
+        q.i = a.lo + t * OT + (tid >> 6) * 32 + (lane & 31);
+        q.valid = q.i < a.hi;
+        q.ic = q.valid ? q.i : a.hi - 1;
+        q.voff = 0; q.base = nullptr;
+        return q;
+    };
     // BITS: X comes as bit planes; a "stage" is then one 32-bit word = eight lookup groups, all
     // (up to four) words of the next tile being loaded with the first stage
     const int W = (P + 31) / 32;
@@ -583,7 +602,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     uint32_t st[STG];
 #pragma unroll
     for (int u = 0; u < STG; ++u) st[u] = 0;
-    TilePos pos = tile_pos(a, has_tile ? tile : 0, NT, tid, lane);
+    TilePos pos = tpos(has_tile ? tile : 0);
     // first loads of the first tile go out before the tables are staged
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     if (has_tile) {
@@ -656,7 +675,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
             const int64_t next = tile + gridDim.x;
             const bool has_next = next < ntiles;  // uniform
-            const TilePos npos = tile_pos(a, has_next ? next : tile, NT, tid, lane);
+            const TilePos npos = tpos(has_next ? next : tile);
             uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             int zo_next = -1;
             const int zoc = zo < 0 ? 0 : zo;
@@ -664,9 +683,9 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             // ---- scoring: K * G conflict-free LDS lookups.  One outer iteration = one feature
             // stage: its loads for the NEXT tile are issued first, fly during the four lookup
             // groups of THIS tile, and are packed last -- nothing in flight is loop-carried.
-            double acc[KT];
+            double acc[KH];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[k] = 0.0;
+            for (int k = 0; k < KH; ++k) acc[k] = 0.0;
             double acc_own = 0.0;
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
@@ -681,18 +700,18 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 #pragma unroll 1
                 for (int g = h * GPSX; g < g_hi; ++g) {
                     const unsigned nib = BITS ? (cur >> ((g & 7) * 4)) & 15u : nibble_of(g, b0, b1, b2, b3);
-                    const volatile lds_f64* row = Tp + ((size_t)g * KT * kGroupM + nib);
+                    const volatile lds_f64* row = Tp + (((size_t)g * KT + kb) * kGroupM + nib);
                     double own = 0.0;
                     if (MINUS == 1) own = TmL[((size_t)g * KT + zoc) * kGroupM + nib];
                     if (MINUS == 2) own = TmG[((size_t)g * KT + zoc) * kGroupM + nib];
 #pragma unroll
-                    for (int c0 = 0; c0 < KT; c0 += CH) {
+                    for (int c0 = 0; c0 < KH; c0 += CH) {
                         double tv[CH];
 #pragma unroll
                         for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * kGroupM];
 #pragma unroll
                         for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
-                        if (CH < KT) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
+                        if (CH < KH) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
                     }
                     if (has_minus) acc_own = acc_own + own;
                 }
@@ -704,34 +723,47 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             const double cm_own = Cm[zoc];
             double m = neg_inf();
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                double sc = Cp[k] + acc[k];
-                if (has_minus && k == zo) sc = cm_own + acc_own;
+            for (int k = 0; k < KH; ++k) {
+                double sc = Cp[kb + k] + acc[k];
+                if (has_minus && kb + k == zo) sc = cm_own + acc_own;
                 acc[k] = sc;
                 m = __builtin_fmax(m, sc);  // v_max_f64; scores are never NaN
             }
+            if (SPLIT == 2) m = __builtin_fmax(m, __shfl_xor(m, 32));
             double tot = 0.0;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
+            for (int k = 0; k < KH; ++k) {
                 const double w = exp_nonpos_tab(acc[k] - m, ET);
                 acc[k] = w;
                 tot = tot + w;
                 if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries
             }
+            double cdf = 0.0;
+            if (SPLIT == 2) {
+                // the running sum goes through the categories in label order: the upper half continues
+                // from the lower half's total
+                const double lower = __shfl(tot, lane & 31);
+                double run = lower;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) run = run + acc[k];
+                tot = __shfl(run, (lane & 31) + 32);
+                cdf = half ? lower : 0.0;
+            }
             const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + pos.ic), a.sweep);
             const double t = u * tot;
-            double cdf = 0.0;
             int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
+            for (int k = 0; k < KH; ++k) {
                 cdf = cdf + acc[k];
                 cnt += t >= cdf ? 1 : 0;
             }
+            if (SPLIT == 2) cnt += __shfl_xor(cnt, 32);
             int zn = cnt;
             if (__any(cnt >= KT)) {  // u * tot rounded up to tot: the last category with weight
                 int last = -1;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) last = acc[k] > 0.0 ? k : last;
+                for (int k = 0; k < KH; ++k) last = acc[k] > 0.0 ? kb + k : last;
+                if (SPLIT == 2) { const int o = __shfl_xor(last, 32); last = o > last ? o : last; }
                 zn = cnt < KT ? cnt : last;
             }
             if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
@@ -752,11 +784,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             DIAG({ const unsigned long long n_ = diag_stamp(); d_draw += n_ - d_t; d_t = n_; })
 
             DIAG(d_nmov += __popcll(__ballot(pos.valid && zn >= 0 && zn != zo));)
-            count_movers(pos.valid && zn >= 0 && zn != zo, zo, zn, b0, b1, b2, b3, hist, K, P, lane);
+            count_movers(pos.valid && half == 0 && zn >= 0 && zn != zo, zo, zn, b0, b1, b2, b3, hist, K, P, lane);
             DIAG({ const unsigned long long n_ = diag_stamp(); d_mov += n_ - d_t; d_t = n_; })
 
             zn_prev = zn;
-            i_prev = pos.valid ? pos.i : -1;
+            i_prev = pos.valid && half == 0 ? pos.i : -1;
             if (!has_next) break;
             b0 = n0; b1 = n1; b2 = n2; b3 = n3;
             zo = zo_next;

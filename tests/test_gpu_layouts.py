@@ -77,3 +77,33 @@ def _capi_set(c, layout):
     import ctypes
     from bmm_mcmc_amd import _capi
     _capi.check(_capi.lib().bmm_chain_set_x_layout(c._h, ctypes.c_int(layout)))
+
+
+# more than 32 accumulators: two lanes share an observation (SPLIT = 2), with and without the
+# own-cluster tables; the one-lane kernels (BMM_DEBUG_NOSPLIT) must give the same chain
+@pytest.mark.parametrize("nosplit", [False, True])
+def test_wide_category_counts_two_lanes_per_observation(oracle, monkeypatch, nosplit):
+    if nosplit:
+        monkeypatch.setenv("BMM_DEBUG_NOSPLIT", "1")
+    else:
+        monkeypatch.delenv("BMM_DEBUG_NOSPLIT", raising=False)
+    for N, P, K, batch in [(3000, 40, 40, 700), (2011, 20, 64, 2011), (1500, 33, 56, 97)]:
+        X, _, _, _ = synth(N, P, 4, K)
+        z0 = _z0(N, K, 3)
+        got = bm.gibbs_collapsed(X, 6, K, burnin=0, seed=77, batch=batch, initial_K=z0)
+        want = oracle.collapsed(X, z0, 6, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=77, batch=batch)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, N, P, K)
+    X, _, _, _ = synth(4000, 24, 5, 9)
+    got = bm.gibbs_dp(X, 8, burnin=0, maxK=47, seed=31, batch=333)
+    want = oracle.dp(X, 8, 0.0, 0.5, 0.5, 1, 1, 0, 47, seed=31, batch=333)
+    for k in ("z", "theta", "alpha"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    rng = np.random.default_rng(4)
+    pi0 = rng.dirichlet(np.ones(40))
+    th0 = rng.random((40, 30))
+    X, _, _, _ = synth(2500, 30, 3, 2)
+    got = bm.gibbs_full(X, 5, 40, burnin=0, seed=6, initial_pi=pi0, initial_theta=th0)
+    want = oracle.full(X, pi0, th0, 5, 40, 0.0, 0.5, 0.5, 1, 1, 0, seed=6)
+    for k in ("z", "theta", "alpha", "pi"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
