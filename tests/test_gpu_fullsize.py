@@ -57,6 +57,16 @@ def test_c5_collapsed_K20_N1e7_P100_statistics_are_a_recount_of_the_labels():
     z3 = ch3.labels()
     ch3.close()
     assert not np.array_equal(z[:1000000], z3[:1000000])
+    del X3
+    # the int32 layout (X streamed as handed over) runs the same chain as the bit planes
+    # (same batch: the defaulted one is rounded to each layout's own workgroup size)
+    ch4, X4, _ = _chain(bm, synth, torch, "c5", 1000, 4, x_layout="int32", batch=1310720)
+    ch5, X5, _ = _chain(bm, synth, torch, "c5", 1000, 4, x_layout="bits", batch=1310720)
+    assert ch4.x_layout() == "int32" and ch5.x_layout() == "bits"
+    z4, z5 = ch4.labels(), ch5.labels()
+    ch4.close()
+    ch5.close()
+    assert np.array_equal(z4, z5)
 
 
 @pytest.mark.timeout(600)
