@@ -271,8 +271,8 @@ int chain_alloc(bmm_chain* c) {
     HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz, c->stream));  // -1 = unassigned
     HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
 #ifdef BMM_DIAG
-    HIP_TRY(hipMalloc(&c->dDiag, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->dDiag, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMalloc(&c->dDiag, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->dDiag, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
@@ -560,13 +560,16 @@ void bmm_chain_destroy(bmm_chain* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
 #ifdef BMM_DIAG
     if (c->dDiag) {
-        unsigned long long d[8];
+        unsigned long long d[16];
         if (hipMemcpy(d, c->dDiag, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && d[5]) {
             const double tot = (double)(d[0] + d[1] + d[2] + d[3] + d[4]);
             fprintf(stderr, "[bmm diag] waves=%llu cycles/wave: score %.0f (%.1f%%) pack %.0f (%.1f%%) draw %.0f (%.1f%%) movers %.0f (%.1f%%) prologue %.0f (%.1f%%) movers/wave-launch %.2f\n",
                     d[5], d[0] / (double)d[5], 100 * d[0] / tot, d[1] / (double)d[5], 100 * d[1] / tot, d[2] / (double)d[5],
                     100 * d[2] / tot, d[3] / (double)d[5], 100 * d[3] / tot, d[4] / (double)d[5], 100 * d[4] / tot, d[6] / (double)d[5]);
         }
+        if (hipMemcpy(d, c->dDiag, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && d[5])
+            fprintf(stderr, "[bmm diag launch] ticks per wave and launch: table staging %.0f, tile loop %.0f, waiting for the workgroup %.0f, flush %.0f\n",
+                    d[8] / (double)d[5], d[9] / (double)d[5], d[10] / (double)d[5], d[11] / (double)d[5]);
         (void)hipFree(c->dDiag);
     }
 #endif

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     constexpr int CH = SPLIT == 2 ? (KH <= 20 ? KH : KH / 2)
                                   : (KT <= 24 ? KT : (KT <= 48 ? KT / 2 : KT / 4));  // lookups issued together
     static_assert(KH % CH == 0, "chunking");
+    DIAG(const unsigned long long d_entry = diag_stamp();)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool has_minus = MINUS != 0;
     const TableLayout L{p.G, KT, has_minus ? 1 : 0};
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         }
     }
 
-    DIAG(unsigned long long d_nmov = 0, d_ntile = 0; unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp();)
+    DIAG(unsigned long long d_nmov = 0, d_ntile = 0; unsigned long long d_score = 0, d_pack = 0, d_draw = 0, d_mov = 0, d_pro = 0; unsigned long long d_t = diag_stamp(); const unsigned long long d_staged = d_t;)
     if (has_tile) {
         // prologue: the rest of the first tile's features, nothing to overlap with yet
         if (!BITS) put_stage<STG>(pack_stage<STG>(P, 0, st), 0, b0, b1, b2, b3);
@@ -798,12 +799,18 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
     }
 
+    DIAG(const unsigned long long d_loop = diag_stamp();)
     __syncthreads();
+    DIAG(const unsigned long long d_sync = diag_stamp();)
     flush_hist(hist, K, P, a.dS, a.dNk, tid, NT);
+    DIAG(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long d_flush = diag_stamp();)
     DIAG(if (a.diag && lane == 0) {
         atomicAdd(&a.diag[0], d_score); atomicAdd(&a.diag[1], d_pack); atomicAdd(&a.diag[2], d_draw);
         atomicAdd(&a.diag[3], d_mov); atomicAdd(&a.diag[4], d_pro); atomicAdd(&a.diag[5], 1ull);
         atomicAdd(&a.diag[6], d_nmov);
+        // per-launch phases of a wave: table staging, tile loop, wait for the workgroup, flush
+        atomicAdd(&a.diag[8], d_staged - d_entry); atomicAdd(&a.diag[9], d_loop - d_staged);
+        atomicAdd(&a.diag[10], d_sync - d_loop); atomicAdd(&a.diag[11], d_flush - d_sync);
     })
 }
 
