@@ -255,18 +255,18 @@ int chain_alloc(bmm_chain* c) {
     HIP_TRY(hipMalloc(&c->dZ[1], nz));
     const size_t ns = (size_t)p.K * p.P * sizeof(int32_t), nn = (size_t)p.K * sizeof(int32_t);
     HIP_TRY(hipMalloc(&c->dNk, nn));
-    HIP_TRY(hipMalloc(&c->dDNk, nn));
+    HIP_TRY(hipMalloc(&c->dDNk, nn * kDeltaReps));
     HIP_TRY(hipMalloc(&c->dS, ns));
-    HIP_TRY(hipMalloc(&c->dDS, ns));
+    HIP_TRY(hipMalloc(&c->dDS, ns * kDeltaReps));
     HIP_TRY(hipMalloc(&c->dAlpha, sizeof(double)));
     HIP_TRY(hipMalloc(&c->dTab, (size_t)layout_of(c).doubles() * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dPi, (size_t)p.K * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dTheta, (size_t)p.K * p.P * sizeof(double)));
     if (c->generic) HIP_TRY(hipMalloc(&c->dScratch, (size_t)c->scratch_stride * p.Kc * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->dNk, 0, nn, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dDNk, 0, nn, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dDNk, 0, nn * kDeltaReps, c->stream));
     HIP_TRY(hipMemsetAsync(c->dS, 0, ns, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dDS, 0, ns, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dDS, 0, ns * kDeltaReps, c->stream));
     HIP_TRY(hipMemsetAsync(c->dTab, 0, (size_t)layout_of(c).doubles() * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz, c->stream));  // -1 = unassigned
     HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -314,6 +314,15 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     return BMM_OK;
 }
 
+// replicas 1.. of the delta accumulators folded into replica 0: what the host-side accessors and the
+// sharded chain's all-reduce read
+int launch_reduce_deltas(bmm_chain* c) {
+    const int n = c->p.K * c->p.P + c->p.K;
+    hipLaunchKernelGGL(k_reduce_deltas, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->p, c->dDNk, c->dDS);
+    HIP_TRY(hipGetLastError());
+    return BMM_OK;
+}
+
 int launch_count_tables(bmm_chain* c) {
     hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(320), 0, c->stream, c->p, c->dNk, c->dS,
                        c->dDNk, c->dDS, c->dAlpha, c->dTab);
@@ -337,7 +346,7 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
             int rc = launch_resample(c, zin, zout, 0, p.N, (uint32_t)j);
             if (rc) return rc;
         }
-        if (phase == 1) return BMM_OK;  // sharded chain: the caller all-reduces the deltas now
+        if (phase == 1) return launch_reduce_deltas(c);  // sharded chain: the caller all-reduces replica 0 now
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
                            al_tr, nk_tr);
@@ -812,7 +821,10 @@ int bmm_chain_get_labels(bmm_chain* c, int32_t* z1) {
 
 int bmm_chain_get_counts(bmm_chain* c, int32_t* Nk, int32_t* S) {
     if (!c || !Nk || !S) return set_err(BMM_E_ARG, "null argument");
-    int rc = bmm_chain_sync(c);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_reduce_deltas(c);
+    if (rc) return rc;
+    rc = bmm_chain_sync(c);
     if (rc) return rc;
     const size_t K = (size_t)c->p.K, KP = K * c->p.P;
     std::vector<int32_t> d(KP > K ? KP : K);

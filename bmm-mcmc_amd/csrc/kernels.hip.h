@@ -71,6 +71,26 @@ struct ChainParams {
     uint64_t seed;
 };
 
+// The integer delta accumulators exist kDeltaReps times (replica r of dS at dS + r*K*P, of dNk at
+// dNk + r*K).  Workgroup b of a launch adds into replica b % kDeltaReps: at the end of a short
+// launch every workgroup flushes its histogram at the same moment, and device-scope atomics on one
+// word serialise (about 12 ns each), so 250 workgroups on the same 1-2 k words cost microseconds;
+// eight replicas cut the queue per word eightfold.  Consumers sum (and clear) the replicas.
+constexpr int kDeltaReps = 8;
+__device__ __forceinline__ int32_t delta_take(int32_t* d, size_t idx, size_t stride) {
+    int32_t v[kDeltaReps];
+#pragma unroll
+    for (int r = 0; r < kDeltaReps; ++r) v[r] = d[idx + r * stride];  // independent loads, one round trip
+    int32_t t = 0;
+#pragma unroll
+    for (int r = 0; r < kDeltaReps; ++r) t += v[r];
+    return t;
+}
+__device__ __forceinline__ void delta_clear(int32_t* d, size_t idx, size_t stride) {
+#pragma unroll
+    for (int r = 0; r < kDeltaReps; ++r) d[idx + r * stride] = 0;
+}
+
 // ---------------------------------------------------------------------------------
 // Table construction: one workgroup per category.  For the counting samplers it first
 // folds the pending integer deltas of its cluster into the statistics.
@@ -103,8 +123,9 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
     // every load this workgroup depends on goes out first, in one round trip: the cluster size
     // (read by every thread: a broadcast, no LDS hand-over), the concentration, the first chunk of counts
     int32_t n_old = 0, n_dl = 0, s_old = 0, s_dl = 0;
-    if (is_label) { n_old = Nk[k]; n_dl = dNk[k]; }
-    if (is_label && dl < P) { s_old = S[(size_t)k * P + dl]; s_dl = dS[(size_t)k * P + dl]; }
+    const size_t KP = (size_t)p.K * P;
+    if (is_label) { n_old = Nk[k]; n_dl = delta_take(dNk, k, p.K); }
+    if (is_label && dl < P) { s_old = S[(size_t)k * P + dl]; s_dl = delta_take(dS, (size_t)k * P + dl, KP); }
     const double alpha = *alpha_ptr;
     const int64_t n = (int64_t)n_old + n_dl;
     const double bg = p.beta + p.gamma;
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
             const int d = c0 + dl;
             double t1 = 0.0, t0 = 0.0;
             if (is_label) {
-                s = c0 == 0 ? s_old + s_dl : S[(size_t)k * P + d] + dS[(size_t)k * P + d];
+                s = c0 == 0 ? s_old + s_dl : S[(size_t)k * P + d] + delta_take(dS, (size_t)k * P + d, KP);
                 if (half == 0) {
                     if (n > 0) {
                         t1 = term_x1(p.beta, s, den_p);
@@ -153,7 +174,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
         if (half == 0 && dl < pc && is_label) {
             const int d = c0 + dl;
             S[(size_t)k * P + d] = s;
-            dS[(size_t)k * P + d] = 0;
+            delta_clear(dS, (size_t)k * P + d, KP);
         }
         write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
         write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
     }
     if (is_label && threadIdx.x == 0) {  // every thread read the old pair before the barriers above
         Nk[k] = (int32_t)n;
-        dNk[k] = 0;
+        delta_clear(dNk, k, p.K);
     }
     if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
 }
@@ -227,11 +248,11 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     __shared__ double v[kMaxCatsAny];
     const int K = p.K, P = p.P;
     for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
-        S[idx] += dS[idx]; dS[idx] = 0;
+        S[idx] += delta_take(dS, idx, (size_t)K * P); delta_clear(dS, idx, (size_t)K * P);
     }
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const int32_t n = Nk[k] + dNk[k];
-        Nk[k] = n; dNk[k] = 0; ck[k] = n;
+        const int32_t n = Nk[k] + delta_take(dNk, k, K);
+        Nk[k] = n; delta_clear(dNk, k, K); ck[k] = n;
         if (nk_trace) nk_trace[k] = n;
     }
     __syncthreads();
@@ -280,6 +301,20 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     }
 }
 
+// Fold replicas 1.. of the delta accumulators into replica 0 and clear them: ahead of anything that
+// hands the deltas to the host or to a collective (bmm_chain_get_counts, bmm_chain_shard_deltas).
+__global__ __launch_bounds__(256) void k_reduce_deltas(ChainParams p, int32_t* __restrict__ dNk,
+                                                       int32_t* __restrict__ dS) {
+    const int KP = p.K * p.P;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KP + p.K) return;
+    int32_t* d = idx < KP ? dS : dNk;
+    const size_t i = idx < KP ? idx : idx - KP, stride = idx < KP ? KP : p.K;
+    const int32_t v = delta_take(d, i, stride);
+    delta_clear(d, i, stride);
+    d[i] = v;
+}
+
 // Counting samplers, end of sweep: fold what the last batch left, theta-hat = S/Nk
 // (NaN for an empty cluster in the finite sampler, 0 for an unused DP label), alpha.
 __global__ __launch_bounds__(1024) void k_count_sweep_end(ChainParams p, int32_t* __restrict__ Nk,
@@ -293,8 +328,8 @@ __global__ __launch_bounds__(1024) void k_count_sweep_end(ChainParams p, int32_t
     __shared__ int32_t nk[kMaxCatsAny];
     const int K = p.K, P = p.P;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const int32_t n = Nk[k] + dNk[k];
-        Nk[k] = n; dNk[k] = 0; nk[k] = n;
+        const int32_t n = Nk[k] + delta_take(dNk, k, K);
+        Nk[k] = n; delta_clear(dNk, k, K); nk[k] = n;
         if (nk_trace) nk_trace[k] = n;
     }
     __syncthreads();
@@ -303,8 +338,8 @@ __global__ __launch_bounds__(1024) void k_count_sweep_end(ChainParams p, int32_t
     const int t0 = blockDim.x > 64 ? (int)threadIdx.x - 64 : (int)threadIdx.x;
     for (int idx = t0 < 0 ? K * P : t0; idx < K * P; idx += nfold) {
         const int k = idx / P, d = idx % P;
-        const int32_t s = S[idx] + dS[idx];
-        S[idx] = s; dS[idx] = 0;
+        const int32_t s = S[idx] + delta_take(dS, idx, (size_t)K * P);
+        S[idx] = s; delta_clear(dS, idx, (size_t)K * P);
         if (theta_trace) {
             double t;
             if (p.mode == MODE_DP && nk[k] == 0) t = 0.0;
@@ -524,7 +559,7 @@ __global__ __launch_bounds__(256) void k_count_labels(ChainParams p, const int32
         count_movers(pos.valid && zl >= 0, -1, zl, b0, b1, b2, b3, hist, K, P, lane);
     }
     __syncthreads();
-    flush_hist(hist, K, P, dS, dNk, tid, 256);
+    flush_hist(hist, K, P, dS + (size_t)(blockIdx.x % kDeltaReps) * K * P, dNk + (blockIdx.x % kDeltaReps) * K, tid, 256);
 }
 
 // Diagnostic build only (-DBMM_DIAG, never shipped): per-wave cycle stamps of the phases.
@@ -802,7 +837,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     DIAG(const unsigned long long d_loop = diag_stamp();)
     __syncthreads();
     DIAG(const unsigned long long d_sync = diag_stamp();)
-    flush_hist(hist, K, P, a.dS, a.dNk, tid, NT);
+    flush_hist(hist, K, P, a.dS + (size_t)(blockIdx.x % kDeltaReps) * K * P, a.dNk + (blockIdx.x % kDeltaReps) * K, tid, NT);
     DIAG(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long d_flush = diag_stamp();)
     DIAG(if (a.diag && lane == 0) {
         atomicAdd(&a.diag[0], d_score); atomicAdd(&a.diag[1], d_pack); atomicAdd(&a.diag[2], d_draw);
@@ -923,12 +958,14 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
         }
         a.z_out[i] = zn;
         if (zn >= 0 && zn != zo) {
-            atomicAdd(&a.dNk[zn], 1);
-            if (zo >= 0) atomicAdd(&a.dNk[zo], -1);
+            int32_t* const rNk = a.dNk + (blockIdx.x % kDeltaReps) * K;
+            int32_t* const rS = a.dS + (size_t)(blockIdx.x % kDeltaReps) * K * P;
+            atomicAdd(&rNk[zn], 1);
+            if (zo >= 0) atomicAdd(&rNk[zo], -1);
             for (int d = 0; d < P; ++d)
                 if (a.X[i + (int64_t)d * p.N] & 1) {
-                    atomicAdd(&a.dS[(size_t)zn * P + d], 1);
-                    if (zo >= 0) atomicAdd(&a.dS[(size_t)zo * P + d], -1);
+                    atomicAdd(&rS[(size_t)zn * P + d], 1);
+                    if (zo >= 0) atomicAdd(&rS[(size_t)zo * P + d], -1);
                 }
         }
     }
