@@ -212,15 +212,14 @@ namespace {
 // (no measurable shift at any batch on well-separated data); the DP sampler opens spurious
 // clusters above about N/16, because every "new" draw of a batch shares one label.
 // every cell of X must be 0 or 1: one streaming pass when the matrix is handed over
-int validate_binary(bmm_chain* c) {
+int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
     int* dflag = nullptr;
     HIP_TRY(hipMalloc(&dflag, sizeof(int)));
     HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), c->stream));
-    const int64_t n = c->p.N * c->p.P;
-    const bool al16 = (reinterpret_cast<uintptr_t>(c->dX) & 15) == 0;
+    const bool al16 = (reinterpret_cast<uintptr_t>(dX) & 15) == 0;
     const int64_t n16 = al16 ? n / 4 : 0;
     hipLaunchKernelGGL(k_validate_binary, dim3(2048), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint4*>(c->dX), n16, reinterpret_cast<const uint32_t*>(c->dX), n, dflag);
+                       reinterpret_cast<const uint4*>(dX), n16, reinterpret_cast<const uint32_t*>(dX), n, dflag);
     int flag = 0;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -450,10 +449,10 @@ int chain_start(bmm_chain* c) {
         const int64_t nt = (p.N + 255) / 256;
         if (c->generic)
             hipLaunchKernelGGL(k_count_labels_generic, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0,
-                               c->stream, p, c->dX, row0, c->dDNk, c->dDS);
+                               c->stream, p, c->dX, c->dXb, row0, c->dDNk, c->dDS);
         else
             hipLaunchKernelGGL(k_count_labels, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), hb, c->stream,
-                               p, c->dX, row0, c->dDNk, c->dDS);
+                               p, c->dX, c->dXb, row0, c->dDNk, c->dDS);
         HIP_TRY(hipGetLastError());
     } else if (explicit_params(p.mode)) {
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
@@ -524,6 +523,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
     const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
+    c->bits = getenv("BMM_X_LAYOUT_INT32") == nullptr;
     c->generic = p.KT < 0 || P > kMaxP || getenv("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {
         c->NT = threads_for(p.KT, false);
@@ -550,7 +550,6 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         c->grid_max = (int)(threads / 256);
     } else {
         c->num_cus = prop.multiProcessorCount;
-        c->bits = getenv("BMM_X_LAYOUT_INT32") == nullptr;
         rc = pick_kernel(c);
         if (rc) { delete c; return rc; }
     }
@@ -591,16 +590,13 @@ void bmm_chain_destroy(bmm_chain* c) {
     delete c;
 }
 
-// X -> bit planes, once per chain (the resident kernels' default layout)
-static int pack_bits(bmm_chain* c) {
-    if (!c->bits || c->generic) return BMM_OK;
-    const int W = (c->p.P + 31) / 32;
-    if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * c->p.N * sizeof(uint32_t)));
-    const int64_t nb = (c->p.N + 255) / 256;
-    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, c->stream, c->dX,
-                       c->p.N, c->p.P, c->dXb);
+// `rows` observations of an int32 matrix (feature d of observation i at X[i + d * ldx]) into the
+// chain's bit planes, starting at observation i0
+static int pack_rows(bmm_chain* c, const int32_t* dX, int64_t rows, int64_t ldx, int64_t i0) {
+    const int64_t nb = (rows + 255) / 256;
+    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, c->stream, dX, rows,
+                       ldx, c->p.P, c->dXb + i0, c->p.N);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
 }
 
@@ -608,8 +604,8 @@ int bmm_chain_set_x_layout(bmm_chain* c, int layout) {
     if (!c) return set_err(BMM_E_ARG, "null chain");
     if (layout != BMM_X_BITPLANES && layout != BMM_X_INT32) return set_err(BMM_E_ARG, "unknown X layout %d", layout);
     if (c->have_data || c->started) return set_err(BMM_E_STATE, "the X layout is chosen before the data are set");
-    if (c->generic) return BMM_OK;  // the generic path reads the matrix as handed over
     c->bits = layout == BMM_X_BITPLANES;
+    if (c->generic) return BMM_OK;  // one kernel for both layouts there
     int rc = pick_kernel(c);
     if (rc) return rc;
     round_default_batch(c);
@@ -618,7 +614,7 @@ int bmm_chain_set_x_layout(bmm_chain* c, int layout) {
 
 int bmm_chain_get_x_layout(const bmm_chain* c, int* layout) {
     if (!c || !layout) return set_err(BMM_E_ARG, "null argument");
-    *layout = c->bits && !c->generic ? BMM_X_BITPLANES : BMM_X_INT32;
+    *layout = c->bits ? BMM_X_BITPLANES : BMM_X_INT32;
     return BMM_OK;
 }
 
@@ -626,15 +622,43 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
     if (!c || !X) return set_err(BMM_E_ARG, "null argument");
     if (c->started) return set_err(BMM_E_STATE, "chain already started");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bytes = (size_t)c->p.N * c->p.P * sizeof(int32_t);
-    if (!c->dX_owned) HIP_TRY(hipMalloc(&c->dX_owned, bytes));
-    HIP_TRY(hipMemcpyAsync(c->dX_owned, X, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->dX = c->dX_owned;
-    int rc = validate_binary(c);
+    const int64_t N = c->p.N;
+    const int P = c->p.P;
+    if (!c->bits) {  // the matrix itself is what the sweeps stream: one copy, kept
+        const size_t bytes = (size_t)N * P * sizeof(int32_t);
+        if (!c->dX_owned) HIP_TRY(hipMalloc(&c->dX_owned, bytes));
+        HIP_TRY(hipMemcpyAsync(c->dX_owned, X, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->dX = c->dX_owned;
+        int rc = validate_binary(c, c->dX, N * P);
+        if (rc) return rc;
+        c->have_data = true;
+        return BMM_OK;
+    }
+    // bit planes: the int32 matrix passes through a staging buffer in slabs of rows (<= 256 MiB) and
+    // never exists whole on the device -- 16 bytes per observation stay instead of 4 P
+    const int W = (P + 31) / 32;
+    if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * N * sizeof(uint32_t)));
+    int64_t slab = ((int64_t)256 << 20) / ((int64_t)P * 4);
+    slab = slab / 4 * 4;
+    if (slab < 4) slab = 4;
+    if (slab > N) slab = N;
+    int32_t* stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, (size_t)slab * P * sizeof(int32_t)));
+    int rc = BMM_OK;
+    for (int64_t i0 = 0; i0 < N && rc == BMM_OK; i0 += slab) {
+        const int64_t rows = N - i0 < slab ? N - i0 : slab;
+        hipError_t e = hipMemcpy2DAsync(stage, (size_t)rows * 4, X + i0, (size_t)N * 4, (size_t)rows * 4, (size_t)P,
+                                        hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = set_err(BMM_E_HIP, "uploading X failed: %s", hipGetErrorString(e)); break; }
+        rc = validate_binary(c, stage, rows * P);  // synchronises the stream
+        if (rc == BMM_OK) rc = pack_rows(c, stage, rows, rows, i0);
+        if (rc == BMM_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(BMM_E_HIP, "packing X failed");
+    }
+    (void)hipFree(stage);
     if (rc) return rc;
-    rc = pack_bits(c);
-    if (rc) return rc;
+    if (c->dX_owned) { (void)hipFree(c->dX_owned); c->dX_owned = nullptr; }
+    c->dX = nullptr;
     c->have_data = true;
     return BMM_OK;
 }
@@ -648,12 +672,20 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
         return set_err(BMM_E_ARG, "dX is not a device pointer");
     }
     if (at.device != c->device) return set_err(BMM_E_ARG, "dX lives on device %d, chain on %d", at.device, c->device);
-    c->dX = static_cast<const int32_t*>(dX);
     HIP_TRY(hipSetDevice(c->device));
-    int rc = validate_binary(c);
+    const int32_t* x = static_cast<const int32_t*>(dX);
+    int rc = validate_binary(c, x, c->p.N * c->p.P);
     if (rc) return rc;
-    rc = pack_bits(c);
-    if (rc) return rc;
+    if (c->bits) {  // packed here and now; the caller's matrix is not read again
+        const int W = (c->p.P + 31) / 32;
+        if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * c->p.N * sizeof(uint32_t)));
+        rc = pack_rows(c, x, c->p.N, c->p.N, 0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->dX = nullptr;
+    } else {
+        c->dX = x;  // borrowed for the life of the chain
+    }
     c->have_data = true;
     return BMM_OK;
 }

@@ -492,16 +492,18 @@ __device__ __forceinline__ void flush_hist(const int32_t* hist, int K, int P, in
 // X as bit planes: word w of observation i (features 32w .. 32w+31, feature d at bit d % 32) at
 // Xb[w * N + i]; bits past P are zero.  X is constant over the whole chain, so the resample kernel
 // streams 4 * ceil(P / 32) bytes per observation and sweep instead of 4 * P.
-__global__ __launch_bounds__(256) void k_pack_bits(const int32_t* __restrict__ X, int64_t N, int P,
-                                                   uint32_t* __restrict__ Xb) {
+__global__ __launch_bounds__(256) void k_pack_bits(const int32_t* __restrict__ X, int64_t rows, int64_t ldx,
+                                                   int P, uint32_t* __restrict__ Xb, int64_t N) {
+    // X: `rows` observations, feature d of observation i at X[i + d * ldx]; Xb already offset to the
+    // first of them, planes N words apart
     const int W = (P + 31) / 32;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
         for (int w = 0; w < W; ++w) {
             uint32_t v = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const int d = w * 32 + j;
-                if (d < P) v |= ((uint32_t)X[i + (int64_t)d * N] & 1u) << j;
+                if (d < P) v |= ((uint32_t)X[i + (int64_t)d * ldx] & 1u) << j;
             }
             Xb[(int64_t)w * N + i] = v;
         }
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(256) void k_validate_binary(const uint4* __restrict
 // Statistics of a given allocation (the collapsed sampler's initial labels,
 // collapsed_gibbs.cpp:60-63): every labelled observation counts as arriving.
 __global__ __launch_bounds__(256) void k_count_labels(ChainParams p, const int32_t* __restrict__ X,
+                                                      const uint32_t* __restrict__ Xb,
                                                       const int32_t* __restrict__ z, int32_t* dNk,
                                                       int32_t* dS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,10 +553,14 @@ __global__ __launch_bounds__(256) void k_count_labels(ChainParams p, const int32
         uint32_t st[16], b0 = 0, b1 = 0, b2 = 0, b3 = 0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) st[u] = 0;
+        if (Xb) {  // bit planes (uniform)
+            load_words(Xb, p.N, (P + 31) / 32, pos.ic, b0, b1, b2, b3);
+        } else {
 #pragma unroll 1
-        for (int h = 0; h < nstages; ++h) {
-            issue_stage<16>(pos, p.N, P, h, st);
-            put_stage<16>(pack_stage<16>(P, h, st), h, b0, b1, b2, b3);
+            for (int h = 0; h < nstages; ++h) {
+                issue_stage<16>(pos, p.N, P, h, st);
+                put_stage<16>(pack_stage<16>(P, h, st), h, b0, b1, b2, b3);
+            }
         }
         const int zl = z[pos.ic];
         count_movers(pos.valid && zl >= 0, -1, zl, b0, b1, b2, b3, hist, K, P, lane);
@@ -856,7 +863,9 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 // scr[k * stride + thread].  Clusters are accumulated sixteen at a time, X is re-read per chunk.
 // Slow next to the resident kernel; it exists so that every shape the reference accepts runs.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned nibble_from_x(const int32_t* X, int64_t N, int P, int64_t i, int g) {
+__device__ __forceinline__ unsigned nibble_from_x(const int32_t* X, const uint32_t* Xb, int64_t N, int P,
+                                                  int64_t i, int g) {
+    if (Xb) return (Xb[(int64_t)(g >> 3) * N + i] >> ((g & 7) * 4)) & 15u;  // bit planes: any number of words
     unsigned nib = 0;
 #pragma unroll
     for (int j = 0; j < kGroupW; ++j) {
@@ -893,14 +902,14 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
         double acc_own = 0.0;
         if (has_minus)
             for (int g = 0; g < G; ++g)
-                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nibble_from_x(a.X, p.N, P, i, g)];
+                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nibble_from_x(a.X, a.Xb, p.N, P, i, g)];
         double m = neg_inf();
         for (int k0 = 0; k0 < Kc; k0 += 16) {
             double acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
             for (int g = 0; g < G; ++g) {
-                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + nibble_from_x(a.X, p.N, P, i, g);
+                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + nibble_from_x(a.X, a.Xb, p.N, P, i, g);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (k0 + j < Kc) acc[j] = acc[j] + row[j * kGroupM];
@@ -963,7 +972,7 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
             atomicAdd(&rNk[zn], 1);
             if (zo >= 0) atomicAdd(&rNk[zo], -1);
             for (int d = 0; d < P; ++d)
-                if (a.X[i + (int64_t)d * p.N] & 1) {
+                if (a.Xb ? (a.Xb[(int64_t)(d >> 5) * p.N + i] >> (d & 31)) & 1u : (uint32_t)a.X[i + (int64_t)d * p.N] & 1u) {
                     atomicAdd(&rS[(size_t)zn * P + d], 1);
                     if (zo >= 0) atomicAdd(&rS[(size_t)zo * P + d], -1);
                 }
@@ -972,6 +981,7 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
 }
 
 __global__ __launch_bounds__(256) void k_count_labels_generic(ChainParams p, const int32_t* __restrict__ X,
+                                                              const uint32_t* __restrict__ Xb,
                                                               const int32_t* __restrict__ z, int32_t* dNk,
                                                               int32_t* dS) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -979,7 +989,8 @@ __global__ __launch_bounds__(256) void k_count_labels_generic(ChainParams p, con
         if (zl < 0) continue;
         atomicAdd(&dNk[zl], 1);
         for (int d = 0; d < p.P; ++d)
-            if (X[i + (int64_t)d * p.N] & 1) atomicAdd(&dS[(size_t)zl * p.P + d], 1);
+            if (Xb ? (Xb[(int64_t)(d >> 5) * p.N + i] >> (d & 31)) & 1u : (uint32_t)X[i + (int64_t)d * p.N] & 1u)
+                atomicAdd(&dS[(size_t)zl * p.P + d], 1);
     }
 }
 

@@ -91,16 +91,18 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K /* K 
                      double alpha, double beta, double gamma, double a, double b, int64_t batch,
                      uint64_t seed, int device);
 void bmm_chain_destroy(bmm_chain* c);
-/* How the resample kernel streams X.  X is constant over the chain, so by default it is packed
- * once, when it is handed over, into bit planes (ceil(P/32) 32-bit words per observation: 24
- * instead of 408 bytes per observation and sweep at P = 100); BMM_X_INT32 streams the
- * IntegerMatrix layout R hands over in place (no second copy, no packing pass).  Same chain
- * either way.  To be chosen before the data are set; shapes on the generic path always read int32. */
+/* How the sweeps read X.  X is constant over the chain, so by default it is packed once, when
+ * it is handed over, into bit planes (ceil(P/32) 32-bit words per observation: 24 instead of 408
+ * bytes per observation and sweep at P = 100) and the int32 matrix is not kept: host data pass
+ * through a staging buffer in slabs of rows, a matrix already on the device is read once and not
+ * again after bmm_chain_set_data_device returns.  BMM_X_INT32 streams the IntegerMatrix layout R
+ * hands over in place instead (no packing pass; a device matrix stays borrowed for the life of
+ * the chain).  Same chain either way.  To be chosen before the data are set. */
 #define BMM_X_BITPLANES 0
 #define BMM_X_INT32 1
 int bmm_chain_set_x_layout(bmm_chain* c, int layout);
 int bmm_chain_get_x_layout(const bmm_chain* c, int* layout);
-/* X from host memory (copied) or already on this device (borrowed; caller keeps it alive) */
+/* X from host memory or already on this device (see the layouts above for what is kept) */
 int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X);
 int bmm_chain_set_data_device(bmm_chain* c, const void* dX);
 /* starting state: collapsed needs 1-based labels; stick-breaking needs pi and theta;
