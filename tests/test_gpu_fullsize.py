@@ -121,3 +121,45 @@ def test_host_matrix_uploaded_in_slabs_equals_the_device_matrix_packed_at_once()
     with bm.Chain("collapsed", N, P, K, seed=3) as c:  # straight through the C ABI (the wrapper checks too)
         rc = _capi.lib().bmm_chain_set_data_host(c._h, _capi.vp(bad))
         assert rc == 1 and b"binary" in _capi.lib().bmm_last_error()  # BMM_E_ARG
+
+
+@pytest.mark.timeout(600)
+def test_posterior_recovers_the_generating_mixture_at_the_default_batch():
+    """North-star acceptance on cluster proportions, at sizes the oracle cannot reach: with the default
+    batch (N/8; N/16 for the DP sampler) the chain must find the mixture the synthetic data were drawn
+    from -- sorted posterior-mean proportions within 0.01 of the generating weights, a draw of the labels
+    agreeing with the generating ones (up to a permutation) as often as a draw from the exact posterior
+    under the generating parameters would (within one point), and the DP sampler holding exactly the
+    generating number of clusters larger than N/1000."""
+    import torch
+    import bmm_mcmc_amd as bm
+    from bmm_mcmc_amd import synth
+    dev = torch.device("cuda", 0)
+    for sampler, K, K_true, N, P, burn, keep in (("collapsed", 3, 3, 100_000, 20, 150, 100),
+                                                  ("dp", 30, 5, 400_000, 50, 150, 60)):
+        X, truth = synth.device_matrix(N, P, K_true, 77, dev)
+        w, theta = synth.truth(K_true, P, 77)
+        ch = bm.Chain(sampler, N, P, K, seed=11)
+        ch.set_data_device(X.data_ptr(), keepalive=X)
+        if sampler == "collapsed":
+            ch.set_initial_labels(np.random.default_rng(1).integers(1, K + 1, N).astype(np.int32))
+        ch.sweeps(burn)
+        counts = ch.sweeps_counts(keep)            # (keep, K) cluster sizes after each sweep, from the device
+        z = ch.labels()
+        ch.close()
+        props = np.sort(counts / N, axis=1)[:, ::-1].mean(axis=0)
+        np.testing.assert_allclose(props[:K_true], np.sort(w)[::-1], atol=0.01)
+        assert props[K_true:].sum() < 0.005
+        if sampler == "dp":  # a CRP keeps opening and closing singletons; the clusters of any size are the true ones
+            assert ((counts > N // 1000).sum(axis=1) == K_true).all()
+        # agreement with the generating labels up to relabelling: each found cluster -> its majority truth
+        t = truth.cpu().numpy()
+        agree = sum(np.bincount(t[z == k + 1], minlength=K_true).max() for k in range(K) if (z == k + 1).any())
+        # what a draw from p(z | x, generating w and theta) would score: the mean posterior mass of the truth
+        th = torch.as_tensor(theta, dtype=torch.float64, device=dev)
+        Xf = X.to(torch.float64)                                                  # (P, N)
+        logp = torch.log(th) @ Xf + torch.log1p(-th) @ (1.0 - Xf)                 # (K_true, N)
+        logp += torch.log(torch.as_tensor(w, dtype=torch.float64, device=dev))[:, None]
+        post = torch.softmax(logp, dim=0)
+        expected = post[truth, torch.arange(N, device=dev)].mean().item()
+        assert agree / N >= expected - 0.01, (agree / N, expected)
