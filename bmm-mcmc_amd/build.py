@@ -10,8 +10,10 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(HERE, "cs
 LIB = os.path.join(HERE, "lib", "libbmmmcmc_hip.so")
 
 # -ffp-contract=off: the spec arithmetic (csrc/bmm_spec.h) fuses only where it says fma_
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wl,-rpath,/opt/rocm/lib"]
+# -amdgpu-sched-strategy=iterative-ilp: the resample kernels are VALU-issue-bound with LDS reads to
+#   hide; this list scheduler measured +2 % on C5 (both layouts) over the default, same results
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm",
+         "-amdgpu-sched-strategy=iterative-ilp", "-fPIC", "-shared", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def hipcc():

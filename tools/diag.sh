@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/.."
 L=bmm-mcmc_amd/lib
 if [ "$1" = build ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DBMM_DIAG \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp -fPIC -shared -DBMM_DIAG \
     -Wl,-rpath,/opt/rocm/lib -o $L/libbmmmcmc_hip_diag.so bmm-mcmc_amd/csrc/chain.hip
   exit 0
 fi
