@@ -346,7 +346,7 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
             if (rc) return rc;
         }
         if (phase == 1) return launch_reduce_deltas(c);  // sharded chain: the caller all-reduces replica 0 now
-        hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(256), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
+        hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(1024), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
                            al_tr, nk_tr);
         HIP_TRY(hipGetLastError());

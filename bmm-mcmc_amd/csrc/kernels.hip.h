@@ -237,7 +237,7 @@ __global__ __launch_bounds__(128) void k_sb_theta_tables(ChainParams p, const in
 
 // Stick-breaking: fold deltas, v_k ~ Beta(1 + c_k, alpha + sum_{l>k} c_l), pi by stick
 // breaking, K_viable, alpha (stickbreaking.cpp:164-214, 233-235).  One workgroup.
-__global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __restrict__ Nk,
+__global__ __launch_bounds__(1024) void k_sb_params(ChainParams p, int32_t* __restrict__ Nk,
                                                    int32_t* __restrict__ S, int32_t* __restrict__ dNk,
                                                    int32_t* __restrict__ dS, double* __restrict__ alpha_ptr,
                                                    double* __restrict__ pi, uint32_t sweep,
@@ -247,9 +247,6 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     __shared__ int32_t ck[kMaxCatsAny];
     __shared__ double v[kMaxCatsAny];
     const int K = p.K, P = p.P;
-    for (int idx = threadIdx.x; idx < K * P; idx += blockDim.x) {
-        S[idx] += delta_take(dS, idx, (size_t)K * P); delta_clear(dS, idx, (size_t)K * P);
-    }
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + delta_take(dNk, k, K);
         Nk[k] = n; delta_clear(dNk, k, K); ck[k] = n;
@@ -257,7 +254,15 @@ __global__ __launch_bounds__(256) void k_sb_params(ChainParams p, int32_t* __res
     }
     __syncthreads();
     const double alpha_prev = *alpha_ptr;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    // the first wave draws the sticks (they need the cluster sizes only) while the others fold the
+    // feature counts, which only the next kernel reads
+    const int nfold = blockDim.x > 64 ? blockDim.x - 64 : blockDim.x;
+    const int t0 = blockDim.x > 64 ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+    for (int idx = t0 < 0 ? K * P : t0; idx < K * P; idx += nfold) {
+        S[idx] += delta_take(dS, idx, (size_t)K * P); delta_clear(dS, idx, (size_t)K * P);
+    }
+    const int ndraw = blockDim.x > 64 ? 64 : blockDim.x;
+    for (int k = threadIdx.x < (unsigned)ndraw ? threadIdx.x : K; k < K; k += ndraw) {
         Stream sa = make_stream(p.seed, (uint32_t)k, sweep, kStreamStickA);
         if (p.mode == MODE_FULL) {
             // pi ~ Dirichlet(alpha/K + c_k) through gammas (full_gibbs.cpp:10-27, 203-210)
