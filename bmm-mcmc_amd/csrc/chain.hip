@@ -350,7 +350,7 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
                            al_tr, nk_tr);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
+        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(256), 0, c->stream, p, c->dNk, c->dS,
                            c->dPi, c->dTheta, 1, (uint32_t)j, th_tr, c->dTab);
         HIP_TRY(hipGetLastError());
         return BMM_OK;
@@ -455,7 +455,7 @@ int chain_start(bmm_chain* c) {
                                p, c->dX, c->dXb, row0, c->dDNk, c->dDS);
         HIP_TRY(hipGetLastError());
     } else if (explicit_params(p.mode)) {
-        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(128), 0, c->stream, p, c->dNk, c->dS,
+        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(256), 0, c->stream, p, c->dNk, c->dS,
                            c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab);
         HIP_TRY(hipGetLastError());
     }

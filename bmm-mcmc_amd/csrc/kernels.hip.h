@@ -189,48 +189,53 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
 
 // Stick-breaking: theta_kd ~ Beta(beta + V_kd, gamma + c_k - V_kd) (stickbreaking.cpp:217-229),
 // unless draw == 0 (initial theta is used as given), then the tables of cluster k.
-__global__ __launch_bounds__(128) void k_sb_theta_tables(ChainParams p, const int32_t* __restrict__ Nk,
+__global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const int32_t* __restrict__ Nk,
                                                          const int32_t* __restrict__ S,
                                                          const double* __restrict__ pi,
                                                          double* __restrict__ theta, int draw,
                                                          uint32_t sweep, double* __restrict__ theta_trace,
                                                          double* __restrict__ tab) {
-    __shared__ double e1[kMaxP], e0[kMaxP];
+    // 256 threads: a Beta draw is X / (X + Y) of two gammas on their own streams, so threads 0-127 draw
+    // X and log theta for feature d while threads 128-255 draw Y and log(1 - theta): half the latency
+    __shared__ double e1[kMaxP], e0[kMaxP], gam[2][kMaxP];
     const int k = blockIdx.x;
     const TableLayout L{p.G, p.KT, 0};
     const int P = p.P, K = p.K;
     const bool is_label = k < K;
+    const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
+    if (threadIdx.x == 255) {  // the constants, ahead of its own feature (if P reaches 128)
+        tab[L.cp() + k] = is_label ? log_(pi[k]) : neg_inf();
+        tab[L.cm() + k] = neg_inf();
+        reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
+    }
     for (int c0 = 0; c0 < P; c0 += kMaxP) {
         const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
-        for (int dl = threadIdx.x; dl < pc; dl += blockDim.x) {
-            const int d = c0 + dl;
-            double a1 = 0.0, a0 = 0.0;
+        const int d = c0 + dl;
+        if (draw && is_label && dl < pc) {
+            const int32_t ck = Nk[k], V = S[(size_t)k * P + d];
+            const uint32_t c0s = (uint32_t)((size_t)k * P + d);
+            Stream st = make_stream(p.seed, c0s, sweep, half ? kStreamThetaB : kStreamThetaA);
+            gam[half][dl] = rgamma_(half ? (p.gamma + (double)ck) - (double)V : p.beta + (double)V, st);
+        }
+        __syncthreads();
+        if (dl < pc) {
+            double t = 0.0;
             if (is_label) {
-                double th;
-                if (draw) {
-                    const int32_t ck = Nk[k], V = S[(size_t)k * P + d];
-                    const uint32_t c0s = (uint32_t)((size_t)k * P + d);
-                    Stream sa = make_stream(p.seed, c0s, sweep, kStreamThetaA);
-                    Stream sb = make_stream(p.seed, c0s, sweep, kStreamThetaB);
-                    th = rbeta_(p.beta + (double)V, (p.gamma + (double)ck) - (double)V, sa, sb);
-                    theta[k + (size_t)d * K] = th;
+                const double x = gam[0][dl];
+                const double th = draw ? div_(x, x + gam[1][dl]) : theta[k + (size_t)d * K];  // rbeta_
+                if (half == 0) {
+                    if (draw) theta[k + (size_t)d * K] = th;
+                    if (theta_trace) theta_trace[k + (size_t)d * K] = th;
+                    t = log_(th);
                 } else {
-                    th = theta[k + (size_t)d * K];
+                    t = log_(1.0 - th);
                 }
-                if (theta_trace) theta_trace[k + (size_t)d * K] = th;
-                a1 = log_(th);
-                a0 = log_(1.0 - th);
             }
-            e1[dl] = a1; e0[dl] = a0;
+            if (half == 0) e1[dl] = t; else e0[dl] = t;
         }
         __syncthreads();
         write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        tab[L.cp() + k] = is_label ? log_(pi[k]) : neg_inf();
-        tab[L.cm() + k] = neg_inf();
-        reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
     }
     if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
 }
