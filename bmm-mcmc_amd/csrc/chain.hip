@@ -134,7 +134,7 @@ resample_fn resample_kernel_at(int kt, int nt, int minus, bool bits) {
     return nullptr;
 }
 // more than 32 accumulators on bit planes: two lanes per observation (SPLIT = 2 in kernels.hip.h)
-constexpr int kThreadsSplit = 768;
+constexpr int kThreadsSplit = 1024;
 template <int MINUS>
 resample_fn resample_kernel_split(int kt) {
     switch (kt) {
