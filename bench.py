@@ -132,6 +132,25 @@ def main():
              "X": X, "chain": ch, "layout": ch.x_layout()}
         return m
 
+    def copy_rate():
+        """GB/s (read + write) of a plain device-to-device copy in this run, on this box: the achievable
+        HBM rate SURVEY.md 8d asks to report beside the 8 TB/s spec."""
+        n = 1 << 28  # 1 GiB of int32 each way
+        a = torch.empty(n, dtype=torch.int32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        del a, b
+        torch.cuda.empty_cache()
+        return 2 * n * 4 / (ms * 1e-3) / 1e9
+
     def sweep_bytes(N, P, layout):
         """bytes of the layout streamed + 4 B old label + 4 B new label, per observation."""
         return N * ((4 * ((P + 31) // 32) if layout == "bits" else 4 * P) + 8)
@@ -182,6 +201,10 @@ def main():
                          "algorithmic_bytes_per_sweep": bytes_per_sweep,
                          "lds_bytes": shape["lds_bytes"], "threads": shape["threads"]},
         }
+        copy_gbps = copy_rate() if world == 1 else None
+        if copy_gbps:
+            result["roofline"]["copy_kernel_GBps"] = copy_gbps
+            result["roofline"]["frac_of_copy_kernel"] = achieved / copy_gbps if achieved else None
         if layout == "bits":
             # labelled secondary: what an int32-streaming kernel would have to move in this time
             result["roofline"]["layout"] = "bit planes"
@@ -230,7 +253,8 @@ def main():
                                  "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / args.steps,
                                  "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": gbps / HBM_PEAK_GBS, "traffic": tr,
-                                              "algorithmic_bytes_per_sweep": bps}}
+                                              "algorithmic_bytes_per_sweep": bps,
+                                              "frac_of_copy_kernel": (gbps / copy_gbps) if copy_gbps else None}}
             e["chain"].close()
             del e
             torch.cuda.empty_cache()
