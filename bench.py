@@ -8,22 +8,33 @@
 A step is one Gibbs sweep: every z_n resampled once, sufficient statistics and
 parameters refreshed.  Default workload "c5" is BASELINE.json's HBM-roofline
 configuration, one chain per GPU: gibbs_collapsed, K=20, N=1e7, P=100, synthetic.
-The data matrix is generated in HBM on rank 0 and broadcast over RCCL (the only
-collective on this path); chains are independent, so scaling is weak.
+The data matrix is generated in HBM on rank 0 and handed to that rank's chain, which packs
+it into bit planes; the planes (160 MB, not the 4 GB int32 matrix) are broadcast once over
+RCCL -- the only collective on this path; chains are independent, so scaling is weak.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the z-resample kernel, timed with HIP
-events on the chain's own stream inside the timed region.  Algorithmic bytes follow SURVEY.md
-section 8d for the layout ACTUALLY streamed: by default X is packed once into bit planes when
-it is handed over, so a sweep streams N*(4*ceil(P/32)+8) bytes (bit-plane words + z read + z
-write); the int32-equivalent figure N*(4P+8) is reported only as a labelled secondary, and the
-kernel that streams the int32 matrix as R hands it over (--x-layout int32) is measured beside
-the headline in `other_workloads`.
-`cpu_baseline` is the oracle's sufficient-statistics chain (same batch semantics) on the
-host cores of this box, on a bounded row sample, scaled to sweeps/s at the workload's N.
+Prints ONE JSON line on rank 0.
+  roofline       the dominant kernel, k_resample, timed with HIP events on the chain's own stream
+                 inside the timed region.  With X in bit planes (the default layout) the kernel is bound
+                 by fp64 VALU issue, not by HBM: `bound` says so, `achieved`/`peak` are VALU
+                 wave-instructions per second (instructions per 64 observations from the rocprofv3
+                 SQ_INSTS_VALU pass under profiles/, x the observations a launch processes, / the
+                 launch time measured here), and the HBM figure of SURVEY.md section 8d for the
+                 layout actually streamed is kept beside it as hbm_frac.  The kernel that streams
+                 the int32 matrix as R hands it over IS HBM-bound and is measured in the same run
+                 (other_workloads.c5_int32, bound "hbm").
+  cpu_baseline   the oracle's sufficient-statistics chain (same batch semantics) on the host cores
+                 of this box: one chain per thread on as many threads as this process may use, up
+                 to one socket's cores; on a bounded row sample, scaled to sweeps/s at the
+                 workload's N.  `literal_1thread` is the reference algorithm as written (member-list
+                 recomputation, O(N^2 P) per sweep), timed at small N and EXTRAPOLATED.
+  other_workloads  the other BASELINE configurations and the north-star shape in the same run
+                 (single GPU only): c2, c3, c4, ns (with its own cpu_baseline), four chains sharing
+                 one GPU, the PCIe-inclusive drop-in call, the rate from a random start.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,7 +42,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+# full-rate VALU issue: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+
+
+def socket_cores():
+    """(cores of one socket, threads this process may run on)"""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = None
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line.lower().startswith("core(s) per socket"):
+                cores = int(line.split(":")[1])
+    except Exception:
+        pass
+    return cores or avail, avail
 
 
 def main():
@@ -41,7 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--burn", type=int, default=30,
                     help="untimed set-up sweeps before the warm-up, so that the timed region is the "
-                         "chain's steady state and not its first sweeps from a random allocation")
+                         "chain's steady state and not its first sweeps from a random allocation "
+                         "(those are reported as from_random_start)")
     ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5", "ns"])
     ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
@@ -49,16 +77,18 @@ def main():
     ap.add_argument("--x-layout", default="bits", choices=["bits", "int32"],
                     help="what the resample kernel streams: bit planes packed once at hand-over (default) "
                          "or the int32 matrix as R hands it over")
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="resident chains per GPU over one copy of the bit planes, each on its own stream")
     ap.add_argument("--event-stride", type=int, default=4, help="time the resample launches of every n-th sweep")
     ap.add_argument("--no-events", action="store_true",
                     help="debug: no HIP events around the resample launches (roofline is then null)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / north-star side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other_workloads)")
     ap.add_argument("--shard", action="store_true",
                     help="ONE chain whose rows are split over the ranks (stick-breaking / full workloads "
                          "only; strong scaling, one all-reduce of the statistics per sweep)")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of a baseline leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,41 +113,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, steps, warmup, burn, batch_arg, n_override=0, k_override=0, x_layout="bits"):
-        """One chain per rank on `workload`; returns timing of `steps` sweeps (max over ranks)."""
+    def profile_info(key):
+        """per-workload constants measured with rocprofv3 (profiles/traffic.json): HBM bytes per launch
+        from the PMC counters, VALU wave-instructions per 64 observations"""
+        try:
+            v = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+            return v if isinstance(v, dict) else None
+        except Exception:
+            return None
+
+    def measure(workload, steps, warmup, burn, batch_arg, n_override=0, k_override=0, x_layout="bits", nchains=1,
+                random_start=0):
+        """`nchains` chains per rank on `workload`; timing of `steps` sweeps of every chain (max over ranks)."""
         sampler, K, K_true, N, P, dseed = synth.WORKLOADS[workload]
         if n_override:
             N = n_override
         if k_override:
             K = k_override
             K_true = min(K_true, K)
-        # data: generated in HBM on rank 0, broadcast once over RCCL/xGMI
+        chains = [bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
+                           batch=batch_arg if batch_arg > 0 else None,
+                           seed=multi.chain_seed(1000, rank * nchains + c),  # chain seeds 1000 + c (SURVEY.md 8d)
+                           device=local, x_layout=x_layout) for c in range(nchains)]
+        ch = chains[0]
+        # data: generated in HBM on rank 0 and handed to its chain; what is broadcast is the packed planes
+        X = None
         if rank == 0:
             X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
+        if x_layout == "bits":
+            multi.broadcast_planes(ch, X, src=0)
+            for c in chains[1:]:
+                c.share_data(ch)
         else:
-            X = torch.empty((P, N), dtype=torch.int32, device=dev)
-        multi.broadcast_data(X, src=0)
-        torch.cuda.synchronize()
-        seed = multi.chain_seed(1000, rank)  # chain seeds 1000 + c (SURVEY.md section 8d)
-        ch = bm.Chain(sampler, N, P, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1,
-                      batch=batch_arg if batch_arg > 0 else None, seed=seed, device=local, x_layout=x_layout)
-        ch.set_data_device(X.data_ptr(), keepalive=X)
-        rng = np.random.default_rng(seed)
-        if sampler == "collapsed":
-            ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
-        elif sampler in ("stickbreaking", "full"):
-            pi0 = np.exp(rng.random(K))
-            ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
-        ch.sweeps(burn)
-        ch.sweeps(warmup)
-        ch.sync()
+            if rank != 0:
+                X = torch.empty((P, N), dtype=torch.int32, device=dev)
+            multi.broadcast_data(X, src=0)
+            for c in chains:
+                c.set_data_device(X.data_ptr(), keepalive=X)
+        for ci, c in enumerate(chains):
+            rng = np.random.default_rng(multi.chain_seed(1000, rank * nchains + ci))
+            if sampler == "collapsed":
+                c.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+            elif sampler in ("stickbreaking", "full"):
+                pi0 = np.exp(rng.random(K))
+                c.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+        first = None
+        if random_start:  # the first sweeps from a random allocation (more movers, every cell flushed)
+            ch.sweeps(0)
+            ch.sync()
+            t0 = time.perf_counter()
+            ch.sweeps(random_start)
+            ch.sync()
+            first = random_start / (time.perf_counter() - t0)
+            burn = max(0, burn - random_start)
+
+        def run(n):
+            if nchains == 1:
+                ch.sweeps(n)
+            else:
+                bm.sweep_chains(chains, n)
+
+        run(burn)
+        run(warmup)
+        for c in chains:
+            c.sync()
         # HIP events around the resample launches of every 4th timed sweep: the per-launch average
         # is what the roofline needs, and 16 event records per sweep would cost ~7 % of the sweep
         ch.profile(0 if args.no_events else args.event_stride)
         barrier()
         t0 = time.perf_counter()
-        ch.sweeps(steps)
-        ch.sync()
+        run(steps)
+        for c in chains:
+            c.sync()
         barrier()
         t1 = time.perf_counter()
         kern_ms, kern_n = ch.profile_read()
@@ -126,11 +193,15 @@ def main():
         lps = 1 if sampler in ("stickbreaking", "full") else -(-N // ch.batch)
         per_launch = (kern_ms / kern_n) if kern_n else 0.0
         kern_ms = multi.max_over_ranks(per_launch * lps * steps)  # resample-kernel ms over the timed sweeps
-        kern_n = lps * steps
-        m = {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
-             "dt": multi.max_over_ranks(t1 - t0), "kern_ms": kern_ms, "kern_n": kern_n,
-             "X": X, "chain": ch, "layout": ch.x_layout()}
-        return m
+        return {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
+                "dt": multi.max_over_ranks(t1 - t0), "kern_ms": kern_ms, "kern_n": lps * steps, "lps": lps,
+                "X": X, "chains": chains, "layout": ch.x_layout(), "first": first, "nchains": nchains}
+
+    def close(m):
+        for c in m["chains"][1:] + m["chains"][:1]:  # borrowers of the planes first
+            c.close()
+        m["X"] = None
+        torch.cuda.empty_cache()
 
     def copy_rate():
         """GB/s (read + write) of a plain device-to-device copy in this run, on this box: the achievable
@@ -155,29 +226,94 @@ def main():
         """bytes of the layout streamed + 4 B old label + 4 B new label, per observation."""
         return N * ((4 * ((P + 31) // 32) if layout == "bits" else 4 * P) + 8)
 
+    def roofline_of(m, steps, key):
+        """roofline object of one measurement (see the module docstring)"""
+        N, P, layout, kern_ms = m["N"], m["P"], m["layout"], m["kern_ms"]
+        if not kern_ms:
+            return None
+        secs = kern_ms * 1e-3
+        bps = sweep_bytes(N, P, layout)
+        gbps = bps * steps / secs / 1e9
+        info = profile_info(key) or {}
+        out = {"kernel": "k_resample", "kernel_ms_per_sweep": kern_ms / steps, "launches_per_sweep": m["lps"],
+               "lds_bytes": m["shape"]["lds_bytes"], "threads": m["shape"]["threads"],
+               "algorithmic_bytes_per_sweep": bps, "traffic": info.get("hbm_bytes_per_launch")}
+        if layout == "int32":
+            out.update({"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbps / HBM_PEAK_GBS})
+            return out
+        vpw = info.get("valu_inst_per_64_obs")
+        out.update({"bound": "valu_f64_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
+                    "hbm_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBS,
+                    "layout": "bit planes: %d bytes per observation and sweep" % (bps // N)})
+        if vpw:
+            ginst = vpw * (N / 64.0) * steps / secs / 1e9
+            out.update({"achieved": ginst, "frac": ginst / VALU_PEAK_GINST, "valu_inst_per_64_obs": vpw,
+                        "valu_source": info.get("source")})
+        else:
+            out.update({"achieved": None, "frac": None})
+        out["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 layout and is bound "
+                       "by fp64 VALU issue (K*ceil(P/4) table adds + K exponentials per observation), not by HBM: "
+                       "achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/) / launch time "
+                       "measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  hbm_frac is SURVEY.md 8d's figure "
+                       "for the bytes this layout streams; the HBM-bound kernel is other_workloads.c5_int32")
+        return out
+
+    def cpu_leg(sampler, Xdev, K, N, batch, label):
+        """the oracle's sufficient-statistics chain on this box's cores; literal form extrapolated"""
+        from oracle import oracle
+        per_socket, avail = socket_cores()
+        threads = max(1, min(per_socket, avail))
+        rows = min(args.cpu_rows, N)
+        Xh = np.asfortranarray(Xdev[:, :rows].t().cpu().numpy())  # first `rows` (shuffled) rows
+        cb = max(1, min(batch, rows))
+        probe = oracle.time_sweeps(sampler, Xh, K, 1, cb, 1000, threads)  # size the leg to ~cpu-seconds
+        cpu_sweeps = int(max(2, min(200, round(args.cpu_seconds / max(probe, 1e-3)))))
+        secs = oracle.time_sweeps(sampler, Xh, K, cpu_sweeps, cb, 1000, threads)
+        alloc_s = threads * rows * cpu_sweeps / secs
+        out = {"value": alloc_s / N, "unit": "sweeps/s", "cores": threads, "kind": "port",
+               "sample": "%s: %d independent chains (one per thread) x %d sweeps over the first %d rows; "
+                         "allocations/s / N" % (label, threads, cpu_sweeps, rows),
+               "allocations_per_s": alloc_s, "seconds": secs,
+               "cores_per_socket": per_socket, "cpus_available_to_this_process": avail}
+        if threads < per_socket:
+            out["one_socket_extrapolated"] = {
+                "value": alloc_s / N * per_socket / threads,
+                "note": "EXTRAPOLATION: this process may use %d of the socket's %d cores; measured rate x %d/%d, "
+                        "assuming the port scales ideally" % (avail, per_socket, per_socket, threads)}
+        if sampler == "collapsed":
+            # the reference algorithm as written, one thread: c * N^2 * P per sweep, fitted at small N
+            P = Xh.shape[1]
+            pts = []
+            for n in (1000, 2000):
+                Xs = np.asfortranarray(Xh[:n])
+                z0 = np.random.default_rng(0).integers(1, K + 1, n).astype(np.int32)
+                t0 = time.perf_counter()
+                oracle.collapsed(Xs, z0, 3, K, 1.0, 0.5, 0.5, 1, 1, 0, seed=1, literal=True)
+                pts.append((n, (time.perf_counter() - t0) / 2))
+            c = float(np.mean([t / (n * n * P) for n, t in pts]))
+            out["literal_1thread"] = {
+                "value": 1.0 / (c * N * N * P), "unit": "sweeps/s", "cores": 1, "kind": "port",
+                "note": "EXTRAPOLATION of the reference algorithm as written (member lists recomputed per "
+                        "(i, k, d), src/collapsed_gibbs.cpp:99-129): c * N^2 * P with c = %.3g s fitted at "
+                        "N = 1000 and 2000 (%.3f s, %.3f s per sweep)" % (c, pts[0][1], pts[1][1])}
+        return out
+
     if args.shard:
         return bench_sharded(args, world, rank, local, dev, barrier)
-    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k, args.x_layout)
-    sampler, K, N, P, batch, shape = m["sampler"], m["K"], m["N"], m["P"], m["batch"], m["shape"]
-    dt, kern_ms, kern_n, X, ch = m["dt"], m["kern_ms"], m["kern_n"], m["X"], m["chain"]
+    rs = 3 if (args.workload in ("c5", "ns", "c2") and args.chains_per_gpu == 1 and args.x_layout == "bits") else 0
+    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k, args.x_layout,
+                nchains=args.chains_per_gpu, random_start=rs)
+    sampler, K, N, P, batch = m["sampler"], m["K"], m["N"], m["P"], m["batch"]
+    dt, nch = m["dt"], m["nchains"]
 
     result = None
     if rank == 0:
         layout = m["layout"]
-        bytes_per_sweep = sweep_bytes(N, P, layout)
-        achieved = (bytes_per_sweep * args.steps) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-        eq_bytes = sweep_bytes(N, P, "int32")
-        eq_achieved = (eq_bytes * args.steps) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload + ("" if layout == "int32" else "_bits"))
-            except Exception:
-                traffic = None
+        key = args.workload + ("" if layout == "int32" else "_bits")
         result = {
             "metric": "gibbs_sweeps_per_s",
-            "value": world * args.steps / dt,
+            "value": world * nch * args.steps / dt,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -188,85 +324,81 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
-                       "sampler": sampler, "K": K, "N": N, "P": P, "batch": batch, "chains": world,
-                       "burn_sweeps": args.burn,
+            "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, %d chain%s per GPU" % (
+                           args.workload, sampler, K, N, P, nch, "" if nch == 1 else "s"),
+                       "sampler": sampler, "K": K, "N": N, "P": P, "batch": batch, "chains": world * nch,
+                       "chains_per_gpu": nch, "burn_sweeps": args.burn,
                        "x_layout": ("bit planes, ceil(P/32) words per observation, packed once at hand-over"
                                     if layout == "bits" else "int32 column-major (as R hands it over)"),
-                       "allocations_per_s": world * args.steps * N / dt},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_resample", "kernel_ms_per_sweep": kern_ms / args.steps,
-                         "launches_per_sweep": kern_n / args.steps,
-                         "algorithmic_bytes_per_sweep": bytes_per_sweep,
-                         "lds_bytes": shape["lds_bytes"], "threads": shape["threads"]},
+                       "allocations_per_s": world * nch * args.steps * N / dt},
+            "roofline": roofline_of(m, args.steps, key),
         }
+        if m["first"]:
+            result["from_random_start"] = {
+                "sweeps_per_s": m["first"],
+                "note": "the first 3 sweeps of the chain from a uniformly random allocation (every observation "
+                        "moves, every statistic cell is flushed); `value` is the steady state after %d sweeps" % args.burn}
         copy_gbps = copy_rate() if world == 1 else None
-        if copy_gbps:
+        if copy_gbps and result["roofline"]:
             result["roofline"]["copy_kernel_GBps"] = copy_gbps
-            result["roofline"]["frac_of_copy_kernel"] = achieved / copy_gbps if achieved else None
-        if layout == "bits":
-            # labelled secondary: what an int32-streaming kernel would have to move in this time
-            result["roofline"]["layout"] = "bit planes"
-            result["roofline"]["int32_equivalent"] = {
-                "bytes_per_sweep": eq_bytes, "GBps": eq_achieved,
-                "frac_of_hbm_peak": (eq_achieved / HBM_PEAK_GBS) if eq_achieved else None,
-                "note": "secondary figure, not a roofline fraction: the packed kernel does not move these bytes"}
-            result["roofline"]["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 "
-                                          "layout and is bound by fp64 VALU issue and LDS lookups, not by HBM; the "
-                                          "HBM-bound kernel on the layout R hands over is other_workloads.c5_int32")
-        if not args.no_cpu and world == 1:
-            from oracle import oracle
-            rows = min(args.cpu_rows, N)
-            Xh = np.asfortranarray(X[:, :rows].t().cpu().numpy())  # first `rows` shuffled rows
-            threads = min(os.cpu_count() or 1, 16)
-            cb = max(1, min(batch, rows))
-            probe = oracle.time_sweeps(sampler, Xh, K, 1, cb, 1000, threads)  # size the leg to ~cpu-seconds
-            cpu_sweeps = int(max(2, min(200, round(args.cpu_seconds / max(probe, 1e-3)))))
-            secs = oracle.time_sweeps(sampler, Xh, K, cpu_sweeps, cb, 1000, threads)
-            alloc_s = threads * rows * cpu_sweeps / secs
-            result["cpu_baseline"] = {
-                "value": alloc_s / N, "unit": "sweeps/s", "cores": threads, "kind": "port",
-                "sample": "%d independent chains (one per thread) x %d sweeps over the first %d rows; "
-                          "allocations/s / N" % (threads, cpu_sweeps, rows),
-                "allocations_per_s": alloc_s, "seconds": secs}
+        if not args.no_cpu and world == 1 and m["X"] is not None:
+            result["cpu_baseline"] = cpu_leg(sampler, m["X"], K, N, batch, args.workload)
             result["config"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-    ch.close()
-    del X, m
-    torch.cuda.empty_cache()
-    # the other BASELINE points, measured in the same run (single GPU only): configs[1] and the
-    # north-star shape.  Reported beside the headline, never instead of it.
-    if world == 1 and not args.no_extra and args.workload == "c5" and not (args.n or args.k):
+    close(m)
+    del m
+    # the other BASELINE points, measured in the same run (single GPU only).  Reported beside the
+    # headline, never instead of it.
+    if world == 1 and not args.no_extra and args.workload == "c5" and not (args.n or args.k) and args.chains_per_gpu == 1:
         extra = {}
         if args.x_layout == "bits":
             # the kernel that streams the int32 matrix in place: the HBM-roofline measurement proper
             e = measure("c5", args.steps, args.warmup, args.burn, args.batch, x_layout="int32")
-            bps = sweep_bytes(e["N"], e["P"], "int32")
-            gbps = bps * args.steps / (e["kern_ms"] * 1e-3) / 1e9
-            tr = None
-            try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("c5")
-            except Exception:
-                pass
+            r = roofline_of(e, args.steps, "c5")
+            if r and copy_gbps:
+                r["frac_of_copy_kernel"] = r["achieved"] / copy_gbps
             extra["c5_int32"] = {"workload": "c5 with --x-layout int32 (X streamed as R hands it over)",
                                  "sweeps_per_s": args.steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / args.steps,
-                                 "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / args.steps,
-                                 "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": gbps / HBM_PEAK_GBS, "traffic": tr,
-                                              "algorithmic_bytes_per_sweep": bps,
-                                              "frac_of_copy_kernel": (gbps / copy_gbps) if copy_gbps else None}}
-            e["chain"].close()
+                                 "batch": e["batch"], "roofline": r}
+            close(e)
             del e
-            torch.cuda.empty_cache()
-        for w, steps in (("c2", 200), ("ns", 50)):
-            e = measure(w, steps, 5, args.burn, 0, x_layout=args.x_layout)
+        for w, steps in (("c2", 200), ("c3", 50), ("c4", 50), ("ns", 50)):
+            e = measure(w, steps, 5, args.burn, 0, x_layout=args.x_layout, random_start=3 if w == "ns" else 0)
             bps = sweep_bytes(e["N"], e["P"], e["layout"])
             extra[w] = {"workload": "gibbs_%s K=%d N=%d P=%d" % (e["sampler"], e["K"], e["N"], e["P"]),
                         "sweeps_per_s": steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / steps,
-                        "batch": e["batch"], "kernel_ms_per_sweep": e["kern_ms"] / steps,
-                        "algorithmic_GBps": bps * steps / (e["kern_ms"] * 1e-3) / 1e9,
+                        "batch": e["batch"], "launches_per_sweep": e["lps"],
+                        "kernel_ms_per_sweep": e["kern_ms"] / steps,
+                        "allocations_per_s": steps * e["N"] / e["dt"],
+                        "algorithmic_GBps": bps * steps / (e["kern_ms"] * 1e-3) / 1e9 if e["kern_ms"] else None,
                         "note": "working set %.0f MB: cache-resident, not an HBM measurement" % (bps / 1e6)}
-            e["chain"].close()
+            if w == "ns":
+                if e["first"]:
+                    extra[w]["from_random_start_sweeps_per_s"] = e["first"]
+                if not args.no_cpu and e["X"] is not None:
+                    extra[w]["cpu_baseline"] = cpu_leg(e["sampler"], e["X"], e["K"], e["N"], e["batch"], "ns")
+                    extra[w]["gpu_over_cpu"] = extra[w]["sweeps_per_s"] / extra[w]["cpu_baseline"]["value"]
+            close(e)
+            del e
+        # MCMC practice runs several chains: four resident chains on this GPU over one copy of the planes
+        e = measure("ns", 50, 5, args.burn, 0, x_layout="bits", nchains=4)
+        extra["ns_4chains"] = {"workload": "north-star shape, 4 chains on one GPU (bmm_chain_share_data, "
+                                           "bmm_chains_sweeps: one stream and one host thread per chain)",
+                               "chains_per_gpu": 4, "sweeps_per_s": 4 * 50 / e["dt"],
+                               "ms_per_step_per_chain": 1e3 * e["dt"] / 50,
+                               "vs_single_chain": (4 * 50 / e["dt"]) / extra["ns"]["sweeps_per_s"]}
+        close(e)
+        del e
+        # the drop-in entry point end to end: host matrix in over PCIe, S x N trace out (never `value`)
+        Nn, Pn, Kn = 1_000_000, 50, 20
+        Xh, _, _, _ = synth.host_matrix(Nn, Pn, 20, 22)
+        z0 = np.random.default_rng(0).integers(1, Kn + 1, Nn).astype(np.int32)
+        t0 = time.perf_counter()
+        out = bm.gibbs_collapsed(Xh, 220, Kn, burnin=200, seed=1, initial_K=z0)
+        dt_api = time.perf_counter() - t0
+        extra["ns_end_to_end"] = {"workload": "gibbs_collapsed(host X 200 MB in, 220 sweeps, 20 kept: S x N trace "
+                                              "80 MB out) at the north-star shape, PCIe included",
+                                  "sweeps_per_s": 220 / dt_api, "seconds": dt_api, "kept_sweeps": int(out["z"].shape[0])}
+        del Xh, out
         result["other_workloads"] = extra
     if rank == 0:
         print(json.dumps(result))

@@ -18,7 +18,11 @@ from . import _capi
 from ._capi import BmmError, NA_INTEGER
 
 __all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
-           "default_batch"]
+           "default_batch", "sweep_chains", "TOL_PROPORTIONS", "TOL_THETA"]
+
+# include/bmm_mcmc.h: the stated tolerance of a batch > 1 against the reference's sequential scan
+TOL_PROPORTIONS = 0.015
+TOL_THETA = 0.05
 
 
 def _seed(seed):
@@ -38,14 +42,6 @@ def _burnin(burnin, nsamples):
     return burnin
 
 
-def _no_relabel(relabel):
-    if relabel:
-        raise NotImplementedError(
-            "relabel=TRUE (Stephens 2000b via lp_solve) is host post-processing that stays in the "
-            "reference package (src/stephens.cpp, src/my_lpsolve.cpp); this build does not produce "
-            "the per-sweep probability matrices it consumes yet (SURVEY.md section 8 f2)")
-
-
 def _na_perm(S, K):
     return _np.full((S, K), NA_INTEGER, dtype=_np.int32, order="F")  # uninitialised in the reference
 
@@ -54,130 +50,263 @@ def default_batch(sampler, N):
     return int(_capi.lib().bmm_default_batch(_capi.SAMPLER_CODE[sampler], N))
 
 
+# ---------------------------------------------------------------- relabel = TRUE
+_PROBS_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.POINTER(_C.c_double))
+
+
+class _Hooks(_C.Structure):  # bmm_relabel_hooks
+    _fields_ = [("burnrelabel", _C.c_int), ("probs_batch", _C.c_void_p), ("batch_done", _PROBS_FN),
+                ("on_sample", _PROBS_FN), ("user", _C.c_void_p)]
+
+
+class _Relabel:
+    """The reference's relabel = TRUE bookkeeping (src/collapsed_gibbs.cpp:187-201, 215-217, 232-243) around
+    host code that stays what it is: `stephens` supplies the two functions of src/stephens.h,
+        stephens.batch(p)          p: (N, K, burnrelabel) cube      -> Q (N, K)       my_stephens_batch
+        stephens.online(Q, p, j)   p: (N, K) of sweep j             -> (perm, Q_new)  my_stephens_online
+    (perm 0-based, as arma::Row<int>).  The per-sweep probability matrices come from the device."""
+
+    def __init__(self, stephens, N, K, nsamples, burnin, burnrelabel):
+        if stephens is None:
+            raise NotImplementedError(
+                "relabel=TRUE runs Stephens' relabelling (src/stephens.cpp, src/my_lpsolve.cpp) on the host, and "
+                "that code stays in the reference package: pass stephens=<object with batch(p) and "
+                "online(Q, p, j)> bound to it; this build supplies the probability matrices it consumes")
+        self.st, self.N, self.K, self.burnin = stephens, N, K, burnin
+        self.S = nsamples - burnin
+        self.W = max(0, int(burnrelabel))
+        self.cube = _np.zeros((N, K, max(self.W, 1)), order="F")
+        self.Q = None
+        self.perms = _np.full((self.S, K), NA_INTEGER, dtype=_np.int32, order="F")
+        self.error = None
+        self._batch_cb = _PROBS_FN(self._batch_done)
+        self._sample_cb = _PROBS_FN(self._on_sample)
+        self.hooks = _Hooks(self.W, self.cube.ctypes.data_as(_C.c_void_p), self._batch_cb, self._sample_cb, None)
+
+    def _batch_done(self, user, j, probs):
+        try:
+            self.Q = _np.asarray(self.st.batch(self.cube[:, :, :self.W]), dtype=_np.float64)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            self.error = e
+            return 1
+
+    def _on_sample(self, user, j, probs):
+        try:
+            p = _np.ctypeslib.as_array(probs, shape=(self.K, self.N)).T  # N x K column-major, no copy
+            perm, self.Q = self.st.online(self.Q, p, j)
+            self.perms[j - self.burnin] = _np.asarray(perm, dtype=_np.int32)
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def ref(self):
+        return _C.byref(self.hooks)
+
+    def finish(self, rc, out):
+        if self.error is not None:
+            raise self.error
+        _capi.check(rc)
+        z, theta = out["z"], out["theta"]
+        zr = _np.empty_like(z)
+        thr = _np.empty_like(theta)
+        for s in range(self.S):
+            pm = self.perms[s]
+            zr[s] = pm[z[s] - 1] + 1          # z_out_relabelled(j,i) = perm(z_out(j,i)-1) + 1   (:198)
+            thr[pm, :, s] = theta[:, :, s]    # thetas_relab(perm(k), d, j) = theta(k, d, j)     (:216)
+        out.update(permutations=self.perms, z=zr, theta=thr, z_original=z, theta_original=theta)
+        return out
+
+
+def _clamp_burnrelabel(burnrelabel, burnin):
+    return int(round(0.1 * burnin)) if burnrelabel > burnin else int(burnrelabel)  # R/utils.R:26,41,72
+
+
+def _ptr_table(arrays, ctype=_C.c_void_p):
+    return (ctype * len(arrays))(*[a.ctypes.data for a in arrays])
+
+
+def _devices(chains, devices):
+    if devices is None:
+        return None
+    dv = [int(d) for d in devices]
+    if len(dv) != chains:
+        raise ValueError("devices must name one device per chain")
+    return (_C.c_int * chains)(*dv)
+
+
+def _multi(sampler, X, chains, devices, z0s, pi0s, th0s, nsamples, K, alpha, beta, gamma, a, b, burnin, batch,
+           seed, with_pi):
+    """bmm_multi_run: `chains` independent chains (seed + c) over one upload of the data."""
+    N, P = X.shape
+    S = nsamples - burnin
+    zs = [_np.zeros((S, N), dtype=_np.int32, order="F") for _ in range(chains)]
+    ths = [_np.zeros((K, P, S), order="F") for _ in range(chains)]
+    als = [_np.zeros((S, 1), order="F") for _ in range(chains)]
+    pis = [_np.zeros((S, K), order="F") for _ in range(chains)] if with_pi else None
+    rc = _capi.lib().bmm_multi_run(
+        _C.c_int(_capi.SAMPLER_CODE[sampler]), _C.c_int(chains), _devices(chains, devices), _capi.vp(X),
+        _C.c_int64(N), _C.c_int(P), _ptr_table(z0s) if z0s else None, _ptr_table(pi0s) if pi0s else None,
+        _ptr_table(th0s) if th0s else None, _C.c_int(nsamples), _C.c_int(K),
+        _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma), _C.c_double(a),
+        _C.c_double(b), _C.c_int(burnin), _C.c_int64(0 if batch is None else batch), _C.c_uint64(seed),
+        _ptr_table(pis) if with_pi else None, _ptr_table(zs), _ptr_table(ths), _ptr_table(als))
+    _capi.check(rc)
+    out = []
+    for c in range(chains):
+        d = {"alpha": als[c], "permutations": _na_perm(S, K), "z": zs[c], "theta": ths[c]}
+        if with_pi:
+            d = {"pi": pis[c], **d}
+        out.append(d)
+    return out
+
+
 def gibbs_collapsed(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None,
                     relabel=False, burnrelabel=50, debug=False, *, seed=None, batch=None, device=0,
-                    initial_K=None):
+                    initial_K=None, chains=1, devices=None, stephens=None):
     """Collapsed Gibbs sampler, finite K (R/utils.R:37-47 -> src/collapsed_gibbs.cpp:24).
 
     Extra keyword-only arguments: `seed` (Philox key; default drawn from the global NumPy
     RNG), `batch` (observations resampled per frozen-statistics batch; 1 = the reference's
     sequential scan; None = library default), `device`, `initial_K` (1-based labels; default
-    sampled uniformly as R/utils.R:42 does).
+    sampled uniformly as R/utils.R:42 does), `chains` / `devices` (several independent chains,
+    seed + c, in one call: returns a list of chain objects), `stephens` (the host relabelling
+    code for relabel=True, see _Relabel).
     """
-    _no_relabel(relabel)
     X = _capi.as_x(data)
     N, P = X.shape
     nsamples, K = int(nsamples), int(K)
     burnin = _burnin(burnin, nsamples)
     seed = _seed(seed)
+    chains = int(chains)
+    if chains > 1:
+        if relabel:
+            raise NotImplementedError("relabel=TRUE is offered per chain (chains=1)")
+        z0s = [_np.ascontiguousarray(_np.random.default_rng(seed + c).integers(1, K + 1, N), dtype=_np.int32)
+               for c in range(chains)] if initial_K is None else [_np.ascontiguousarray(z, dtype=_np.int32) for z in initial_K]
+        return _multi("collapsed", X, chains, devices, z0s, None, None, nsamples, K, alpha, beta, gamma, a, b,
+                      burnin, batch, seed, False)
     if initial_K is None:
         initial_K = _np.random.default_rng(seed).integers(1, K + 1, N)
     z0 = _np.ascontiguousarray(initial_K, dtype=_np.int32)
     if z0.shape != (N,):
         raise ValueError("initial_K must have one label per observation")
     S = nsamples - burnin
+    rl = _Relabel(stephens, N, K, nsamples, burnin, _clamp_burnrelabel(burnrelabel, burnin)) if relabel else None
     z = _np.zeros((S, N), dtype=_np.int32, order="F")
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
-    rc = _capi.lib().bmm_collapsed_run(
+    rc = _capi.lib().bmm_collapsed_run_probs(
         _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(z0), _C.c_int(nsamples), _C.c_int(K),
         _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
         _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int64(0 if batch is None else batch),
-        _C.c_uint64(seed), _C.c_int(device), _capi.vp(z), _capi.vp(theta), _capi.vp(al))
+        _C.c_uint64(seed), _C.c_int(device), _capi.vp(z), _capi.vp(theta), _capi.vp(al),
+        rl.ref() if rl else None)
+    out = {"alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
+    if rl:
+        return rl.finish(rc, out)
     _capi.check(rc)
-    return {"alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
+    return out
 
 
 def gibbs_dp(data, nsamples, alpha=None, a=1, b=1, beta=0.5, gamma=0.5, burnin=None, relabel=False,
-             burnrelabel=50, maxK=30, debug=False, *, seed=None, batch=None, device=0):
+             burnrelabel=50, maxK=30, debug=False, *, seed=None, batch=None, device=0, chains=1, devices=None,
+             stephens=None):
     """Collapsed Gibbs sampler with a Dirichlet-process prior, truncated at maxK
     (R/utils.R:23-30 -> src/collapsed_gibbs_dp.cpp:27)."""
-    _no_relabel(relabel)
     X = _capi.as_x(data)
     N, P = X.shape
     nsamples, maxK = int(nsamples), int(maxK)
     burnin = _burnin(burnin, nsamples)
     seed = _seed(seed)
+    if int(chains) > 1:
+        if relabel:
+            raise NotImplementedError("relabel=TRUE is offered per chain (chains=1)")
+        return _multi("dp", X, int(chains), devices, None, None, None, nsamples, maxK, alpha, beta, gamma, a, b,
+                      burnin, batch, seed, False)
     S = nsamples - burnin
+    rl = _Relabel(stephens, N, maxK, nsamples, burnin, _clamp_burnrelabel(burnrelabel, burnin)) if relabel else None
     z = _np.zeros((S, N), dtype=_np.int32, order="F")
     theta = _np.zeros((maxK, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
-    rc = _capi.lib().bmm_dp_run(
+    rc = _capi.lib().bmm_dp_run_probs(
         _capi.vp(X), _C.c_int64(N), _C.c_int(P), _C.c_int(nsamples),
         _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
         _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int(maxK),
         _C.c_int64(0 if batch is None else batch), _C.c_uint64(seed), _C.c_int(device), _capi.vp(z),
-        _capi.vp(theta), _capi.vp(al))
+        _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
+    out = {"alpha": al, "permutations": _na_perm(S, maxK), "z": z, "theta": theta}
+    if rl:
+        return rl.finish(rc, out)
     _capi.check(rc)
-    return {"alpha": al, "permutations": _na_perm(S, maxK), "z": z, "theta": theta}
+    return out
 
 
-def gibbs_stickbreaking(data, nsamples, maxK, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None,
-                        relabel=False, burnrelabel=50, debug=False, *, seed=None, device=0,
-                        initial_pi=None, initial_theta=None):
-    """Blocked Gibbs sampler, truncated stick-breaking prior
-    (R/utils.R:95-107 -> src/stickbreaking.cpp:10)."""
-    _no_relabel(relabel)
-    X = _capi.as_x(data)
-    N, P = X.shape
-    nsamples, maxK = int(nsamples), int(maxK)
-    burnin = _burnin(burnin, nsamples)
-    seed = _seed(seed)
-    rng = _np.random.default_rng(seed)
-    if initial_pi is None:  # R/utils.R:98-100
-        initial_pi = _np.exp(rng.random(maxK))
-        initial_pi = initial_pi / initial_pi.sum()
-    if initial_theta is None:  # R/utils.R:103
-        initial_theta = rng.random(maxK * P).reshape((maxK, P), order="F")
-    pi0 = _np.ascontiguousarray(initial_pi, dtype=_np.float64)
-    th0 = _np.asfortranarray(initial_theta, dtype=_np.float64)
-    if pi0.shape != (maxK,) or th0.shape != (maxK, P):
-        raise ValueError("initial_pi must have maxK entries and initial_theta be maxK x P")
-    S = nsamples - burnin
-    z = _np.zeros((S, N), dtype=_np.int32, order="F")
-    theta = _np.zeros((maxK, P, S), order="F")
-    al = _np.zeros((S, 1), order="F")
-    pi = _np.zeros((S, maxK), order="F")
-    rc = _capi.lib().bmm_sb_run(
-        _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(pi0), _capi.vp(th0), _C.c_int(nsamples),
-        _C.c_int(maxK), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta),
-        _C.c_double(gamma), _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed),
-        _C.c_int(device), _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al))
-    _capi.check(rc)
-    return {"pi": pi, "alpha": al, "permutations": _na_perm(S, maxK), "z": z, "theta": theta}
-
-
-def gibbs_full(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None, relabel=False,
-               burnrelabel=50, debug=False, *, seed=None, device=0, initial_pi=None, initial_theta=None):
-    """Full (uncollapsed) Gibbs sampler, finite K (R/utils.R:64-78 -> src/full_gibbs.cpp:32)."""
-    _no_relabel(relabel)
+def _explicit(sampler, fn, clamp, data, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, seed,
+              device, initial_pi, initial_theta, chains, devices, stephens):
     X = _capi.as_x(data)
     N, P = X.shape
     nsamples, K = int(nsamples), int(K)
     burnin = _burnin(burnin, nsamples)
     seed = _seed(seed)
-    rng = _np.random.default_rng(seed)
-    if initial_pi is None:  # R/utils.R:68-70
-        initial_pi = _np.exp(rng.random(K))
-        initial_pi = initial_pi / initial_pi.sum()
-    if initial_theta is None:  # R/utils.R:74
-        initial_theta = rng.random(K * P).reshape((K, P), order="F")
-    pi0 = _np.ascontiguousarray(initial_pi, dtype=_np.float64)
-    th0 = _np.asfortranarray(initial_theta, dtype=_np.float64)
-    if pi0.shape != (K,) or th0.shape != (K, P):
-        raise ValueError("initial_pi must have K entries and initial_theta be K x P")
+    chains = int(chains)
+
+    def start(sd, pi, th):
+        rng = _np.random.default_rng(sd)
+        if pi is None:  # R/utils.R:68-70, 98-100
+            pi = _np.exp(rng.random(K))
+            pi = pi / pi.sum()
+        if th is None:  # R/utils.R:74, 103
+            th = rng.random(K * P).reshape((K, P), order="F")
+        pi = _np.ascontiguousarray(pi, dtype=_np.float64)
+        th = _np.asfortranarray(th, dtype=_np.float64)
+        if pi.shape != (K,) or th.shape != (K, P):
+            raise ValueError("initial_pi must have K entries and initial_theta be K x P")
+        return pi, th
+
+    if chains > 1:
+        if relabel:
+            raise NotImplementedError("relabel=TRUE is offered per chain (chains=1)")
+        st = [start(seed + c, initial_pi[c] if initial_pi is not None else None,
+                    initial_theta[c] if initial_theta is not None else None) for c in range(chains)]
+        return _multi(sampler, X, chains, devices, None, [p for p, _ in st], [t for _, t in st], nsamples, K,
+                      alpha, beta, gamma, a, b, burnin, None, seed, True)
+    pi0, th0 = start(seed, initial_pi, initial_theta)
     S = nsamples - burnin
+    W = _clamp_burnrelabel(burnrelabel, burnin) if clamp else int(burnrelabel)  # R/utils.R:97-101 has no clamp
+    rl = _Relabel(stephens, N, K, nsamples, burnin, W) if relabel else None
     z = _np.zeros((S, N), dtype=_np.int32, order="F")
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
     pi = _np.zeros((S, K), order="F")
-    rc = _capi.lib().bmm_full_run(
+    rc = getattr(_capi.lib(), fn)(
         _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(pi0), _capi.vp(th0), _C.c_int(nsamples),
-        _C.c_int(K), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
-        _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed), _C.c_int(device),
-        _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al))
+        _C.c_int(K), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta),
+        _C.c_double(gamma), _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed),
+        _C.c_int(device), _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
+    out = {"pi": pi, "alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
+    if rl:
+        return rl.finish(rc, out)
     _capi.check(rc)
-    return {"pi": pi, "alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
+    return out
+
+
+def gibbs_stickbreaking(data, nsamples, maxK, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None,
+                        relabel=False, burnrelabel=50, debug=False, *, seed=None, device=0, initial_pi=None,
+                        initial_theta=None, chains=1, devices=None, stephens=None):
+    """Blocked Gibbs sampler, truncated stick-breaking prior (R/utils.R:95-107 ->
+    src/stickbreaking.cpp:10).  The z-step is exactly parallel, so there is no batch."""
+    return _explicit("stickbreaking", "bmm_sb_run_probs", False, data, nsamples, maxK, alpha, beta, gamma, a, b,
+                     burnin, relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens)
+
+
+def gibbs_full(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None, relabel=False,
+               burnrelabel=50, debug=False, *, seed=None, device=0, initial_pi=None, initial_theta=None, chains=1,
+               devices=None, stephens=None):
+    """Full (uncollapsed) Gibbs sampler, finite K (R/utils.R:64-78 -> src/full_gibbs.cpp:32)."""
+    return _explicit("full", "bmm_full_run_probs", True, data, nsamples, K, alpha, beta, gamma, a, b, burnin,
+                     relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens)
 
 
 class Chain:
@@ -236,6 +365,20 @@ class Chain:
         self._keep = keepalive
         _capi.check(_capi.lib().bmm_chain_set_data_device(self._h, _C.c_void_p(int(ptr))))
 
+    def share_data(self, other):
+        """Borrow the bit planes `other` (same device, N, P) already holds: several chains over one copy."""
+        self._keep = other
+        _capi.check(_capi.lib().bmm_chain_share_data(self._h, other._h))
+
+    def planes(self):
+        """(device address, words) of the chain's bit planes, allocated on first call."""
+        a, n = _C.c_void_p(), _C.c_int64(0)
+        _capi.check(_capi.lib().bmm_chain_planes(self._h, _C.byref(a), _C.byref(n)))
+        return a.value, n.value
+
+    def planes_filled(self):
+        _capi.check(_capi.lib().bmm_chain_planes_filled(self._h))
+
     def set_initial_labels(self, z1):
         z1 = _np.ascontiguousarray(z1, dtype=_np.int32)
         if z1.shape != (self.N,):
@@ -256,8 +399,15 @@ class Chain:
     def set_shard(self, N_total, first_row):
         _capi.check(_capi.lib().bmm_chain_set_shard(self._h, _C.c_int64(N_total), _C.c_int64(first_row)))
 
-    def shard_resample(self):
-        _capi.check(_capi.lib().bmm_chain_shard_resample(self._h))
+    def shard_resample(self, wait=True):
+        fn = _capi.lib().bmm_chain_shard_resample if wait else _capi.lib().bmm_chain_shard_resample_async
+        _capi.check(fn(self._h))
+
+    def stream(self):
+        """The chain's HIP stream handle (for ordering a caller's collective behind it)."""
+        st = _C.c_void_p()
+        _capi.check(_capi.lib().bmm_chain_stream(self._h, _C.byref(st)))
+        return st.value
 
     def shard_deltas(self):
         """Device addresses of the int32 statistic deltas (dNk: K, dS: K*P) to be summed over ranks."""
@@ -327,3 +477,10 @@ class Chain:
         lds, th, g = _C.c_int(0), _C.c_int(0), _C.c_int(0)
         _capi.check(_capi.lib().bmm_chain_kernel_shape(self._h, _C.byref(lds), _C.byref(th), _C.byref(g)))
         return {"lds_bytes": lds.value, "threads": th.value, "grid_max": g.value}
+
+
+def sweep_chains(chains, n):
+    """n more sweeps of every chain in `chains`, one host thread per chain (bmm_chains_sweeps): chains on
+    one device overlap on their streams.  Returns without waiting; sync each chain afterwards."""
+    tab = (_C.c_void_p * len(chains))(*[c._h.value for c in chains])
+    _capi.check(_capi.lib().bmm_chains_sweeps(tab, _C.c_int(len(chains)), _C.c_int(int(n))))

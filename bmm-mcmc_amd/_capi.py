@@ -22,7 +22,9 @@ SYMBOLS = [
     "bmm_chain_shard_deltas", "bmm_chain_shard_finish", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
     "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",
     "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_chain_batch", "bmm_device_math", "bmm_device_variates",
-    "bmm_device_count",
+    "bmm_device_count", "bmm_collapsed_run_probs", "bmm_dp_run_probs", "bmm_sb_run_probs", "bmm_full_run_probs",
+    "bmm_multi_run", "bmm_multi_selfcheck", "bmm_chains_sweeps", "bmm_chain_share_data", "bmm_chain_planes",
+    "bmm_chain_planes_filled", "bmm_chain_shard_resample_async", "bmm_chain_stream",
 ]
 
 
@@ -32,23 +34,35 @@ class BmmError(RuntimeError):
         self.code = code
 
 
+def lib_path():
+    """The product library, unless BMM_LIB_PATH names another build of it (the -DBMM_DEBUG_HOOKS test
+    variant, a diagnostic or experimental build): alternatives are loaded from their own path, the
+    product file is never overwritten."""
+    return os.environ.get("BMM_LIB_PATH") or _build.LIB
+
+
+def load(path):
+    """dlopen one build of the library and declare the non-int signatures."""
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). This package has no CPU fallback.")
+    L = C.CDLL(path)
+    L.bmm_last_error.restype = C.c_char_p
+    L.bmm_default_batch.restype = C.c_int64
+    L.bmm_default_batch.argtypes = [C.c_int, C.c_int64]
+    L.bmm_chain_batch.restype = C.c_int64
+    L.bmm_chain_batch.argtypes = [C.c_void_p]
+    L.bmm_chain_destroy.restype = None
+    L.bmm_chain_destroy.argtypes = [C.c_void_p]
+    L.bmm_chain_share_data.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = _build.LIB
-        if not os.path.exists(path):
-            raise ImportError(
-                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc, gfx950). This package has no CPU fallback.")
-        L = C.CDLL(path)
-        L.bmm_last_error.restype = C.c_char_p
-        L.bmm_default_batch.restype = C.c_int64
-        L.bmm_default_batch.argtypes = [C.c_int, C.c_int64]
-        L.bmm_chain_batch.restype = C.c_int64
-        L.bmm_chain_batch.argtypes = [C.c_void_p]
-        L.bmm_chain_destroy.restype = None
-        L.bmm_chain_destroy.argtypes = [C.c_void_p]
-        _LIB = L
+        _LIB = load(lib_path())
     return _LIB
 
 

@@ -1,4 +1,13 @@
-"""Build recipe for the HIP library (gfx950 only).  hipcc cross-compiles without a GPU."""
+"""Build recipe for the HIP library (gfx950 only).  hipcc cross-compiles without a GPU.
+
+Two variants of the same sources:
+  lib/libbmmmcmc_hip.so      the product: reads no environment, no debug hooks
+  lib/libbmmmcmc_hip_dbg.so  -DBMM_DEBUG_HOOKS: the kernel-steering environment switches the parity
+                             tests use to reach every kernel variant (BMM_DEBUG_GENERIC,
+                             BMM_DEBUG_THREADS, BMM_DEBUG_NOSPLIT, BMM_X_LAYOUT_INT32)
+`BMM_LIB_PATH` makes _capi.py load another build (tools/exp_lib.sh, tools/diag.sh) -- nothing ever
+overwrites the product library in place.
+"""
 import os
 import shutil
 import subprocess
@@ -6,8 +15,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "chain.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(HERE, "csrc", "bmm_spec.h"),
-        os.path.join(os.path.dirname(HERE), "include", "bmm_mcmc.h")]
+        os.path.join(HERE, "csrc", "bmm_exp256.h"), os.path.join(os.path.dirname(HERE), "include", "bmm_mcmc.h")]
 LIB = os.path.join(HERE, "lib", "libbmmmcmc_hip.so")
+LIB_DBG = os.path.join(HERE, "lib", "libbmmmcmc_hip_dbg.so")
 
 # -ffp-contract=off: the spec arithmetic (csrc/bmm_spec.h) fuses only where it says fma_
 # -amdgpu-sched-strategy=iterative-ilp: the resample kernels are VALU-issue-bound with LDS reads to
@@ -23,20 +33,30 @@ def hipcc():
     return exe
 
 
-def stale():
-    return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+def stale(lib=LIB):
+    return (not os.path.exists(lib)) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+def _cmd(lib, extra):
+    return [hipcc()] + FLAGS + list(extra) + ["-o", lib, SRC]
+
+
+def build(force=False, verbose=False, debug_variant=False):
+    """Build the product library (and, with debug_variant, the test variant beside it, in parallel)."""
+    jobs = []
+    for lib, extra, want in ((LIB, [], True), (LIB_DBG, ["-DBMM_DEBUG_HOOKS"], debug_variant)):
+        if want and (force or stale(lib)):
+            os.makedirs(os.path.dirname(lib), exist_ok=True)
+            cmd = _cmd(lib + ".tmp", extra)
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((lib, subprocess.Popen(cmd)))
+    for lib, proc in jobs:
+        if proc.wait() != 0:
+            raise RuntimeError("hipcc failed building " + lib)
+        os.replace(lib + ".tmp", lib)  # never a half-written library under the product's name
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True, debug_variant=True))

@@ -14,9 +14,13 @@
 //   stick-breaking z-step   src/stickbreaking.cpp:75-105
 //   alpha update            src/utils.cpp:6-14
 // The reference draws through R's Mersenne-Twister (rmultinom / rbeta / rgamma); this
-// build draws through Philox4x32-10 (counter-based, Salmon et al. 2011), see DESIGN.md.
+// build draws through Philox (counter-based, Salmon et al. 2011): Philox2x32-10 for the one
+// uniform per observation and sweep that decides z_n, Philox4x32-10 for the parameter variates;
+// see DESIGN.md.
 #pragma once
 #include <stdint.h>
+
+#include "bmm_exp256.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -80,7 +84,32 @@ BMM_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
     U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
 }
 
-// 53-bit uniform in [0,1) from two 32-bit words.
+// Philox2x32-10: one 32x32->64 multiply per round; two output words = the one uniform a
+// categorical draw needs (a 4x32 block would throw half of its four multiplies per round away).
+BMM_HD void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t& o0, uint32_t& o1) {
+    const uint32_t M = 0xD256D193u, W = 0x9E3779B9u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t pr = (uint64_t)M * (uint64_t)c0;
+        c0 = (uint32_t)(pr >> 32) ^ k ^ c1;
+        c1 = (uint32_t)pr;
+        k += W;
+    }
+    o0 = c0; o1 = c1;
+}
+
+// 52-bit uniform in [0,1): the words fill the mantissa of a double in [1,2), minus 1 (no
+// integer-to-double conversions).  Its largest value is 1 - 2^-52, and u * t < t then holds in
+// binary64 for every finite t > 0, so an inverse-CDF walk against t = u * total always ends inside.
+BMM_HD double u52(uint32_t a, uint32_t b) {
+    const uint32_t hi = 0x3ff00000u | (a >> 12);
+    const uint32_t lo = (a << 20) | (b >> 12);
+    return dfrom(((uint64_t)hi << 32) | lo) - 1.0;
+}
+
+// 53-bit uniform in [0,1) from two 32-bit words (parameter variates).
 BMM_HD double u01(uint32_t a, uint32_t b) {
     const double hi = (double)(a >> 5), lo = (double)(b >> 6);
     return (hi * 67108864.0 + lo) * 1.1102230246251565404e-16;  // 2^-53
@@ -98,11 +127,16 @@ BMM_HD Stream make_stream(uint64_t seed, uint32_t c0, uint32_t c2, uint32_t sid)
     s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); return s;
 }
 
-// The uniform that decides z_i in sweep j (one Philox block per observation per sweep).
+// The uniform that decides z_i in sweep j: Philox2x32-10 at counter (i mod 2^32, sweep) under a
+// 32-bit key folded from the 64-bit seed (and from the high word of i, zero below 2^32 observations).
+BMM_HD uint32_t z_key(uint64_t seed, uint64_t i) {
+    const uint32_t h = (uint32_t)(i >> 32);
+    return ((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu)) ^ ((h << 16) | (h >> 16));
+}
 BMM_HD double z_uniform(uint64_t seed, uint64_t i, uint32_t sweep) {
-    const U4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), sweep, kStreamZ,
-                               (uint32_t)seed, (uint32_t)(seed >> 32));
-    return u01(r.x, r.y);
+    uint32_t a, b;
+    philox2x32_10((uint32_t)i, sweep, z_key(seed, i), a, b);
+    return u52(a, b);
 }
 
 // ---------------------------------------------------------------- log / exp
@@ -204,20 +238,42 @@ BMM_HD double exp_tab(double x, Tab T) {
 }
 BMM_HD double exp_(double x) { return exp_tab(x, exp2_table()); }
 
-// exp_ restricted to x <= 0 (the sampler's max-shifted scores): bit-identical to exp_ there,
-// without the overflow and top-of-range handling.  A NaN argument (all scores -inf) gives an
-// unspecified value that the caller discards.
-template <class Tab>
-BMM_HD double exp_nonpos_tab(double x, Tab T) {
-    const bool ok = x >= -708.0;                     // false for NaN too
-    const double xs = __builtin_fmax(x, -708.0);     // NaN -> -708
-    int k;                                           // in [-1022, 0]
-    const double p = exp_core(xs, T, k);
-    // the scale 2^k is built in its high word; an underflowing argument gets scale 0
-    const uint32_t hi = ok ? (uint32_t)(k + 1023) << 20 : 0u;
-    return p * dfrom((uint64_t)hi << 32);
+// The weight exponential of the draw: expw_(x) for x <= 0 (max-shifted scores; -inf and NaN
+// arguments give exactly 0).  256 k + j = round-to-nearest-even(x * 256/ln2) by the 1.5 * 2^52
+// trick (the integer is read from the low word of the sum: no floor, no conversion),
+// r = x - (256 k + j) ln2/256 in two parts, |r| <= ln2/512: e^r - 1 by a degree-4 polynomial
+// (truncation < 2^-54), 2^(j/256) from a 256-entry table of correctly rounded doubles
+// (bmm_exp256.h), the scale 2^k by ldexp.  Arguments below -745.2 underflow to 0 through ldexp's
+// own IEEE rounding; nothing is flushed by a comparison.  Error < 1 ulp in the normal range.
+static const double kExp256Host[256] = {BMM_EXP2_256_TABLE};
+#if defined(__HIPCC__)
+__constant__ double kExp256Dev[256] = {BMM_EXP2_256_TABLE};
+#endif
+BMM_HD const double* exp256_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kExp256Dev;
+#else
+    return kExp256Host;
+#endif
 }
-BMM_HD double exp_nonpos(double x) { return exp_nonpos_tab(x, exp2_table()); }
+BMM_HD double ldexp_(double p, int k) { return __builtin_ldexp(p, k); }
+template <class Tab>
+BMM_HD double expw_tab(double x, Tab T) {
+    const double xs = __builtin_fmax(x, -1000.0);                        // NaN -> -1000
+    const double km = fma_(xs, 0x1.71547652b82fep+8, 6755399441055744.0);  // 256/ln2, 1.5 * 2^52
+    const int32_t ki = (int32_t)(uint32_t)dbits(km);
+    const double kd = km - 6755399441055744.0;
+    double r = fma_(-kd, 0x1.62e42fefa39efp-9, xs);                       // ln2/256, high part
+    r = fma_(-kd, 0x1.abc9e3b39803fp-64, r);                             // low part
+    const int j = ki & 255;
+    const int k = ki >> 8;
+    double c = fma_(r, 4.1666666666666664354e-02, 1.6666666666666665741e-01);  // 1/24, 1/6
+    c = fma_(r, c, 0.5);
+    const double q = fma_(r * r, c, r);
+    const double t = T[j];
+    return ldexp_(fma_(t, q, t), k);
+}
+BMM_HD double expw_(double x) { return expw_tab(x, exp256_table()); }
 
 // ---------------------------------------------------------------- variates
 // Standard normal by the Marsaglia polar method (log and sqrt only).

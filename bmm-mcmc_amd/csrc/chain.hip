@@ -6,6 +6,9 @@
 // the reference's (collapsed_gibbs.cpp:84-225, collapsed_gibbs_dp.cpp:98-283,
 // stickbreaking.cpp:66-236) with the per-observation loop replaced by batches.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen when a run spans devices
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -14,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bmm_mcmc.h"
@@ -24,6 +29,15 @@ using namespace bmm;
 namespace {
 
 thread_local char g_err[512] = "";
+
+// Kernel-steering environment hooks exist only in the test variant of the library
+// (-DBMM_DEBUG_HOOKS, lib/libbmmmcmc_hip_dbg.so, built next to the product by the tests):
+// the product library never reads the environment.
+#ifdef BMM_DEBUG_HOOKS
+const char* dbg_env(const char* name) { return getenv(name); }
+#else
+const char* dbg_env(const char*) { return nullptr; }
+#endif
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -40,6 +54,14 @@ int set_err(int code, const char* fmt, ...) {
             return set_err(BMM_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
                            __FILE__, __LINE__);                                                \
     } while (0)
+
+// device scratch that is released on every return path
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
 
 // accumulator counts the resample kernel is instantiated for
 const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
@@ -145,6 +167,31 @@ resample_fn resample_kernel_split(int kt) {
     }
     return nullptr;
 }
+// The weight-emitting twins (EMIT) of the default-sized bit-plane kernels: what a sweep runs on
+// while its allocation probabilities go to the host (any workgroup size serves any batch).
+template <int MINUS>
+resample_fn resample_kernel_emit_m(int kt) {
+    switch (kt) {
+        case 4: return k_resample<4, kThreadsSmall, MINUS, 16, true, 1, true>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS, 16, true, 1, true>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS, 16, true, 1, true>;
+        case 16: return k_resample<16, kThreadsSmall, MINUS, 16, true, 1, true>;
+        case 20: return k_resample<20, kThreadsSmall, MINUS, 16, true, 1, true>;
+        case 24: return k_resample<24, kThreadsMid, MINUS, 16, true, 1, true>;
+        case 28: return k_resample<28, kThreadsMid, MINUS, 16, true, 1, true>;
+        case 32: return k_resample<32, kThreadsMid, MINUS, 16, true, 1, true>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, true, 1, true>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, true, 1, true>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, true, 1, true>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, true, 1, true>;
+    }
+    return nullptr;
+}
+resample_fn resample_kernel_emit(int kt, int minus) {
+    return minus == 0 ? resample_kernel_emit_m<0>(kt)
+                      : (minus == 1 ? resample_kernel_emit_m<1>(kt) : resample_kernel_emit_m<2>(kt));
+}
+
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
 resample_fn resample_kernel(int kt, int minus, bool bits) {
     if (bits)
@@ -171,19 +218,23 @@ struct bmm_chain {
     bool sharded = false, shard_open = false;  // one chain over several ranks (explicit-parameter samplers)
     bool generic = false;         // shape beyond the resident kernel: tables from global memory
     double* dScratch = nullptr;   // generic path: per-thread score columns
-    double* dProbs = nullptr;     // sweep_probs: N x K probabilities of the sweep being run
-    bool probs_sweep = false;     // route this sweep through the generic kernel and emit dProbs
+    // allocation probabilities for the host's relabelling: while probs_dst is
+    // set, every resample launch also emits its weights (dWts [Kc][N], dWtot [N]) and k_probs_finish
+    // normalises them into probs_dst (N x K column-major, device)
+    double *dProbs = nullptr, *dWts = nullptr, *dWtot = nullptr;
+    double* probs_dst = nullptr;
     int64_t scratch_stride = 0;
     size_t lds_bytes = 0;
     resample_fn fn = nullptr;
+    resample_fn fn_emit = nullptr;  // weight-emitting twin (bit planes), its workgroup size and grid limit
+    int NT_emit = 0, grid_max_emit = 0;
 
     const int32_t* dX = nullptr;
     int32_t* dX_owned = nullptr;
     uint32_t* dXb = nullptr;      // bit planes of X (k_pack_bits), what the resident kernels stream by default
+    bool xb_borrowed = false;     // dXb belongs to another chain on this device (bmm_chain_share_data)
     bool bits = false;
     int num_cus = 0;
-    bool batch_defaulted = false;
-    int64_t batch_unrounded = 0;
     int32_t* dZ[2] = {nullptr, nullptr};
     int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
     double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
@@ -213,8 +264,9 @@ namespace {
 // clusters above about N/16, because every "new" draw of a batch shares one label.
 // every cell of X must be 0 or 1: one streaming pass when the matrix is handed over
 int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
-    int* dflag = nullptr;
-    HIP_TRY(hipMalloc(&dflag, sizeof(int)));
+    DevBuf flagbuf;
+    HIP_TRY(flagbuf.alloc(sizeof(int)));
+    int* const dflag = flagbuf.as<int>();
     HIP_TRY(hipMemsetAsync(dflag, 0, sizeof(int), c->stream));
     const bool al16 = (reinterpret_cast<uintptr_t>(dX) & 15) == 0;
     const int64_t n16 = al16 ? n / 4 : 0;
@@ -224,15 +276,20 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dflag);
     if (e != hipSuccess) return set_err(BMM_E_HIP, "validating X failed: %s", hipGetErrorString(e));
     if (flag) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
     return BMM_OK;
 }
 
+// A pure function of (sampler, N) -- no device, occupancy or layout enters, so a defaulted batch
+// names the same chain everywhere.  Above 2^18 observations (one round of 256 workgroups of 1024
+// on an MI355X) it is rounded up to whole multiples of that, so that the big shapes run whole rounds.
 int64_t default_batch(int sampler, int64_t N) {
     if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
     int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
+    const int64_t round = (int64_t)1 << 18;
+    if (b > round) b = (b + round - 1) / round * round;
+    if (b > N) b = N;
     return b < 1 ? 1 : b;
 }
 
@@ -282,15 +339,17 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     ResampleArgs a{};
     a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
-    const int64_t ntiles = (hi - lo + c->OT - 1) / c->OT;
-    int grid = (int)(ntiles < c->grid_max ? ntiles : c->grid_max);
-    const bool use_generic = c->generic || c->probs_sweep;
+    const bool emit = c->probs_dst != nullptr;
+    const bool use_generic = c->generic || (emit && !c->fn_emit);  // the int32 layout has no emitting twin
+    const int OT = emit ? c->NT_emit : c->OT, gmax = emit ? c->grid_max_emit : c->grid_max;
+    const int64_t ntiles = use_generic ? 1 : (hi - lo + OT - 1) / OT;
+    int grid = (int)(ntiles < gmax ? ntiles : gmax);
     if (use_generic) {
         const int64_t nt256 = (hi - lo + 255) / 256;
         const int64_t maxb = c->scratch_stride / 256;
         grid = (int)(nt256 < maxb ? nt256 : maxb);
-        a.probs = c->probs_sweep ? c->dProbs : nullptr;
     }
+    if (emit) { a.wts = c->dWts; a.wtot = c->dWtot; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof > 0 && sweep % (uint32_t)c->prof == 0) {
         if (c->ev_used + 2 > c->ev.size()) {
@@ -306,10 +365,35 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     if (use_generic)
         hipLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, c->p, a, c->dScratch,
                            c->scratch_stride);
+    else if (emit)
+        hipLaunchKernelGGL(c->fn_emit, dim3(grid), dim3(c->NT_emit), c->lds_bytes, c->stream, c->p, a);
     else
         hipLaunchKernelGGL(c->fn, dim3(grid), dim3(c->NT), c->lds_bytes, c->stream, c->p, a);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (emit) {  // before the next k_count_tables rewrites the image's cluster sizes
+        const int64_t nb = (hi - lo + 255) / 256;
+        hipLaunchKernelGGL(k_probs_finish, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, c->stream, c->p,
+                           c->dTab, c->dWts, c->dWtot, lo, hi, c->probs_dst);
+        HIP_TRY(hipGetLastError());
+    }
+    return BMM_OK;
+}
+
+// buffers of the probability hand-off, allocated on first use
+int probs_alloc(bmm_chain* c, bool with_matrix) {
+    const size_t n = (size_t)c->p.N;
+    if (!c->dWts) HIP_TRY(hipMalloc(&c->dWts, n * c->p.Kc * sizeof(double)));
+    if (!c->dWtot) HIP_TRY(hipMalloc(&c->dWtot, n * sizeof(double)));
+    if (with_matrix && !c->dProbs) HIP_TRY(hipMalloc(&c->dProbs, n * c->p.K * sizeof(double)));
+    if (!c->fn_emit && !c->dScratch) {  // int32 layout: the hand-off sweeps run on the generic kernel
+        int64_t threads = (int64_t)256 * 1024;
+        const int64_t cap = ((int64_t)256 << 20) / ((int64_t)c->p.Kc * 8);
+        if (threads > cap) threads = cap / 256 * 256;
+        if (threads < 256) threads = 256;
+        c->scratch_stride = threads;
+        HIP_TRY(hipMalloc(&c->dScratch, (size_t)threads * c->p.Kc * sizeof(double)));
+    }
     return BMM_OK;
 }
 
@@ -383,12 +467,12 @@ int pick_kernel(bmm_chain* c) {
     c->NT = threads_for(p.KT, c->bits);
     c->fn = resample_kernel(p.KT, minus, c->bits);
     int split = 1;
-    if (c->bits && p.KT > 32 && minus != 2 && !getenv("BMM_DEBUG_NOSPLIT")) {
+    if (c->bits && p.KT > 32 && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
         c->fn = minus ? resample_kernel_split<1>(p.KT) : resample_kernel_split<0>(p.KT);
         c->NT = kThreadsSplit;
         split = 2;
     }
-    if (const char* dbg = getenv("BMM_DEBUG_THREADS")) {
+    if (const char* dbg = dbg_env("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
         if (resample_fn f = resample_kernel_at(p.KT, nt, minus, c->bits)) { c->fn = f; c->NT = nt; }
     } else if (c->bits && split == 1) {
@@ -399,6 +483,16 @@ int pick_kernel(bmm_chain* c) {
         }
     }
     hipError_t e = hipSetDevice(c->device);
+    c->fn_emit = nullptr;
+    if (e == hipSuccess && c->bits) {
+        c->fn_emit = resample_kernel_emit(p.KT, minus);
+        c->NT_emit = threads_for(p.KT, true);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        int pe = 0;
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pe, reinterpret_cast<const void*>(c->fn_emit), c->NT_emit, c->lds_bytes);
+        c->grid_max_emit = (pe < 1 ? 1 : pe) * c->num_cus;
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     int per_cu = 0;
@@ -412,7 +506,7 @@ int pick_kernel(bmm_chain* c) {
     c->OT = c->NT / split;
     const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
     if (split == 1 && tiles < c->num_cus && c->NT > 256 && c->lds_bytes * 4 <= lds_max && minus != 2 &&
-        !getenv("BMM_DEBUG_THREADS")) {
+        !dbg_env("BMM_DEBUG_THREADS")) {
         resample_fn f = resample_kernel_small_of(p.KT, minus, c->bits);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
         int pc2 = 0;
@@ -420,15 +514,6 @@ int pick_kernel(bmm_chain* c) {
         if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->OT = 256; c->grid_max = pc2 * c->num_cus; }
     }
     return BMM_OK;
-}
-
-// a defaulted batch is rounded up to whole rounds of workgroups (no ragged last round)
-void round_default_batch(bmm_chain* c) {
-    if (!c->batch_defaulted) return;
-    const int64_t round = (int64_t)c->grid_max * c->OT;
-    c->batch = c->batch_unrounded;
-    if (c->batch > round) c->batch = (c->batch + round - 1) / round * round;
-    if (c->batch > c->p.N) c->batch = c->p.N;
 }
 
 // things that must be in place before the first sweep
@@ -523,8 +608,8 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
     const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
-    c->bits = getenv("BMM_X_LAYOUT_INT32") == nullptr;
-    c->generic = p.KT < 0 || P > kMaxP || getenv("BMM_DEBUG_GENERIC") != nullptr;
+    c->bits = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
+    c->generic = p.KT < 0 || P > kMaxP || dbg_env("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {
         c->NT = threads_for(p.KT, false);
         c->OT = c->NT;
@@ -553,9 +638,6 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         rc = pick_kernel(c);
         if (rc) { delete c; return rc; }
     }
-    c->batch_defaulted = batch <= 0 && !explicit_params(sampler);
-    c->batch_unrounded = c->batch;
-    round_default_batch(c);
     rc = chain_alloc(c);
     if (rc) { bmm_chain_destroy(c); return rc; }
     *out = c;
@@ -582,8 +664,9 @@ void bmm_chain_destroy(bmm_chain* c) {
     }
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    void* bufs[] = {c->dX_owned, c->dXb, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk, c->dDS, c->dAlpha, c->dTab,
-                    c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace, c->dPiTrace, c->dScratch, c->dProbs};
+    void* bufs[] = {c->dX_owned, c->xb_borrowed ? nullptr : c->dXb, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk,
+                    c->dDS, c->dAlpha, c->dTab, c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace,
+                    c->dPiTrace, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -606,10 +689,7 @@ int bmm_chain_set_x_layout(bmm_chain* c, int layout) {
     if (c->have_data || c->started) return set_err(BMM_E_STATE, "the X layout is chosen before the data are set");
     c->bits = layout == BMM_X_BITPLANES;
     if (c->generic) return BMM_OK;  // one kernel for both layouts there
-    int rc = pick_kernel(c);
-    if (rc) return rc;
-    round_default_batch(c);
-    return BMM_OK;
+    return pick_kernel(c);
 }
 
 int bmm_chain_get_x_layout(const bmm_chain* c, int* layout) {
@@ -643,8 +723,9 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
     slab = slab / 4 * 4;
     if (slab < 4) slab = 4;
     if (slab > N) slab = N;
-    int32_t* stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, (size_t)slab * P * sizeof(int32_t)));
+    DevBuf stagebuf;
+    HIP_TRY(stagebuf.alloc((size_t)slab * P * sizeof(int32_t)));
+    int32_t* const stage = stagebuf.as<int32_t>();
     int rc = BMM_OK;
     for (int64_t i0 = 0; i0 < N && rc == BMM_OK; i0 += slab) {
         const int64_t rows = N - i0 < slab ? N - i0 : slab;
@@ -655,7 +736,6 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
         if (rc == BMM_OK) rc = pack_rows(c, stage, rows, rows, i0);
         if (rc == BMM_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(BMM_E_HIP, "packing X failed");
     }
-    (void)hipFree(stage);
     if (rc) return rc;
     if (c->dX_owned) { (void)hipFree(c->dX_owned); c->dX_owned = nullptr; }
     c->dX = nullptr;
@@ -673,6 +753,9 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
     }
     if (at.device != c->device) return set_err(BMM_E_ARG, "dX lives on device %d, chain on %d", at.device, c->device);
     HIP_TRY(hipSetDevice(c->device));
+    // The chain validates and packs on its own non-blocking stream, which nothing orders after the
+    // stream that produced dX (a torch kernel, an RCCL broadcast still in flight): wait for the device.
+    HIP_TRY(hipDeviceSynchronize());
     const int32_t* x = static_cast<const int32_t*>(dX);
     int rc = validate_binary(c, x, c->p.N * c->p.P);
     if (rc) return rc;
@@ -686,6 +769,46 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
     } else {
         c->dX = x;  // borrowed for the life of the chain
     }
+    c->have_data = true;
+    return BMM_OK;
+}
+
+// ---- bit planes shared between chains, or filled by the caller (a broadcast) ----------------
+int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from) {
+    if (!c || !from) return set_err(BMM_E_ARG, "null argument");
+    if (c->started || c->have_data) return set_err(BMM_E_STATE, "the chain already has its data");
+    if (!from->have_data || !from->bits || !from->dXb) return set_err(BMM_E_STATE, "the source chain holds no bit planes");
+    if (from->device != c->device) return set_err(BMM_E_ARG, "chains on different devices cannot share planes");
+    if (from->p.N != c->p.N || from->p.P != c->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
+    if (!c->bits) return set_err(BMM_E_STATE, "the int32 layout streams the caller's matrix: hand it over instead");
+    c->dXb = from->dXb;
+    c->xb_borrowed = true;
+    c->dX = nullptr;
+    c->have_data = true;
+    return BMM_OK;
+}
+
+int bmm_chain_planes(bmm_chain* c, void** dXb, int64_t* n_words) {
+    if (!c || !dXb) return set_err(BMM_E_ARG, "null argument");
+    if (!c->bits) return set_err(BMM_E_STATE, "the chain streams the int32 layout: it has no bit planes");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t words = (int64_t)((c->p.P + 31) / 32) * c->p.N;
+    if (!c->dXb) {
+        if (c->started) return set_err(BMM_E_STATE, "chain already started");
+        HIP_TRY(hipMalloc(&c->dXb, (size_t)words * sizeof(uint32_t)));
+    }
+    *dXb = c->dXb;
+    if (n_words) *n_words = words;
+    return BMM_OK;
+}
+
+int bmm_chain_planes_filled(bmm_chain* c) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    if (!c->bits || !c->dXb) return set_err(BMM_E_STATE, "no planes to declare filled (bmm_chain_planes first)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // whatever filled them ran on a stream of the caller's
+    c->dX = nullptr;
     c->have_data = true;
     return BMM_OK;
 }
@@ -747,7 +870,7 @@ int bmm_chain_set_shard(bmm_chain* c, int64_t N_total, int64_t first_row) {
     return BMM_OK;
 }
 
-int bmm_chain_shard_resample(bmm_chain* c) {
+static int shard_resample(bmm_chain* c, bool wait) {
     if (!c) return set_err(BMM_E_ARG, "null chain");
     if (!explicit_params(c->p.mode)) return set_err(BMM_E_UNSUPPORTED, "not a shardable sampler");
     if (c->shard_open) return set_err(BMM_E_STATE, "previous sweep not finished (bmm_chain_shard_finish)");
@@ -759,7 +882,15 @@ int bmm_chain_shard_resample(bmm_chain* c) {
     int rc = enqueue_sweep(c, c->sweep + 1, 1);
     if (rc) return rc;
     c->shard_open = true;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the deltas are complete: safe to reduce on any stream
+    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));  // the deltas are complete: safe to reduce on any stream
+    return BMM_OK;
+}
+int bmm_chain_shard_resample(bmm_chain* c) { return shard_resample(c, true); }
+int bmm_chain_shard_resample_async(bmm_chain* c) { return shard_resample(c, false); }
+
+int bmm_chain_stream(bmm_chain* c, void** stream) {
+    if (!c || !stream) return set_err(BMM_E_ARG, "null argument");
+    *stream = c->stream;
     return BMM_OK;
 }
 
@@ -785,22 +916,14 @@ int bmm_chain_sweep_probs(bmm_chain* c, double* probs_out) {
     if (!c || !probs_out) return set_err(BMM_E_ARG, "null argument");
     if (c->sharded) return set_err(BMM_E_STATE, "not available on a sharded chain");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bytes = (size_t)c->p.N * c->p.K * sizeof(double);
-    if (!c->dProbs) HIP_TRY(hipMalloc(&c->dProbs, bytes));
-    if (!c->dScratch) {  // a resident-kernel chain borrows the generic kernel for this sweep
-        int64_t threads = (int64_t)256 * 1024;
-        const int64_t cap = ((int64_t)256 << 20) / ((int64_t)c->p.Kc * 8);
-        if (threads > cap) threads = cap / 256 * 256;
-        if (threads < 256) threads = 256;
-        c->scratch_stride = threads;
-        HIP_TRY(hipMalloc(&c->dScratch, (size_t)threads * c->p.Kc * sizeof(double)));
-    }
-    HIP_TRY(hipMemsetAsync(c->dProbs, 0, bytes, c->stream));
-    c->probs_sweep = true;
-    int rc = bmm_chain_sweeps(c, 1);
-    c->probs_sweep = false;
+    int rc = probs_alloc(c, true);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(probs_out, c->dProbs, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->probs_dst = c->dProbs;
+    rc = bmm_chain_sweeps(c, 1);
+    c->probs_dst = nullptr;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(probs_out, c->dProbs, (size_t)c->p.N * c->p.K * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BMM_OK;
 }
@@ -921,54 +1044,229 @@ int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int
 // ------------------------------------------------------------------ *_run entry points
 namespace {
 
-int run_chain(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0, const double* pi0,
-              const double* theta0, int nsamples, int K, double alpha, double beta, double gamma, double a,
-              double b, int burnin, int64_t batch, uint64_t seed, int device, double* pi_out,
-              int32_t* z_out, double* theta_out, double* alpha_out) {
-    if (!X || !z_out || !theta_out || !alpha_out) return set_err(BMM_E_ARG, "null buffer");
-    if (nsamples < 1) return set_err(BMM_E_ARG, "nsamples must be >= 1");
-    if (burnin < 0 || burnin >= nsamples) return set_err(BMM_E_ARG, "burnin must be in [0, nsamples)");
-    bmm_chain* c = nullptr;
-    int rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
-    if (rc) return rc;
-    struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
+struct RunIO {
+    const int32_t* z0 = nullptr;
+    const double *pi0 = nullptr, *theta0 = nullptr;
+    double* pi_out = nullptr;
+    int32_t* z_out = nullptr;
+    double *theta_out = nullptr, *alpha_out = nullptr;
+};
+
+// trace buffers of a *_run call (owned by the chain, released with it)
+int run_prepare(bmm_chain* c, int nsamples, int burnin) {
+    const int64_t N = c->p.N;
+    const int K = c->p.K, P = c->p.P;
     const int S = nsamples - burnin;
     c->burnin = burnin; c->S = S;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&c->dTrace, (size_t)S * N * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->dThetaTrace, (size_t)S * K * P * sizeof(double)));
     HIP_TRY(hipMalloc(&c->dAlphaTrace, (size_t)S * sizeof(double)));
-    if (explicit_params(sampler)) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
-    rc = bmm_chain_set_data_host(c, X);
+    if (explicit_params(c->p.mode)) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
+    return BMM_OK;
+}
+
+// The sweeps of a run whose allocation probabilities go to the host's relabelling code
+// (collapsed_gibbs.cpp:162-172, 187-201): sweeps burnin - burnrelabel .. burnin - 1 fill the batch
+// cube (through a device ring when it fits, so that those sweeps need no host round trip), then
+// every kept sweep hands its N x K matrix to on_sample -- two device and two pinned host buffers,
+// so that sweep j + 1 runs while the host works on sweep j.
+int run_sweeps_hooked(bmm_chain* c, int nsamples, const bmm_relabel_hooks* h) {
+    const int64_t N = c->p.N;
+    const int K = c->p.K, burnin = c->burnin;
+    const size_t mat = (size_t)N * K, mat_bytes = mat * sizeof(double);
+    // the cube has burnrelabel slices, sweep j in slice j - burnin + burnrelabel (collapsed_gibbs.cpp:163-166);
+    // slices of sweeps that do not exist (j < 1: a window longer than the burn-in, which only the
+    // stick-breaking wrapper lets through, R/utils.R:97-101) stay zero, as arma::fill::zeros leaves them
+    const int W = h->burnrelabel < 0 ? 0 : h->burnrelabel;
+    if (W > 0 && !h->probs_batch) return set_err(BMM_E_ARG, "relabel hooks: probs_batch is null");
+    const int first_window = burnin - W;  // sweep of slice 0
+    for (int q = 0; q < W && q + first_window < 1; ++q) std::memset(h->probs_batch + (size_t)q * mat, 0, mat_bytes);
+    int rc = probs_alloc(c, false);
     if (rc) return rc;
-    if (sampler == BMM_SAMPLER_COLLAPSED) rc = bmm_chain_set_initial_labels(c, z0);
-    if (explicit_params(sampler)) rc = bmm_chain_set_initial_params(c, pi0, theta0);
+    // device ring for the batch window when it takes at most half of the free memory
+    DevBuf ring;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const bool use_ring = W > 0 && mat_bytes * (size_t)W <= free_b / 2;
+    if (use_ring) {
+        HIP_TRY(ring.alloc(mat_bytes * (size_t)W));
+        HIP_TRY(hipMemsetAsync(ring.p, 0, mat_bytes * (size_t)W, c->stream));
+    }
+    DevBuf dbuf[2];
+    double* hbuf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct Pinned { double** h; hipEvent_t* e; ~Pinned() { for (int q = 0; q < 2; ++q) { if (h[q]) (void)hipHostFree(h[q]); if (e[q]) (void)hipEventDestroy(e[q]); } } } pin{hbuf, ev};
+    for (int q = 0; q < 2; ++q) {
+        HIP_TRY(dbuf[q].alloc(mat_bytes));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hbuf[q]), mat_bytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
+    }
+    int pending = -1;  // sweep whose matrix is on its way to hbuf[pending & 1]
+    auto deliver = [&](int jj) -> int {
+        HIP_TRY(hipEventSynchronize(ev[jj & 1]));
+        if (jj < burnin) {  // a window sweep without the ring: straight into the cube
+            std::memcpy(h->probs_batch + (size_t)(jj - first_window) * mat, hbuf[jj & 1], mat_bytes);
+            return BMM_OK;
+        }
+        if (h->on_sample && h->on_sample(h->user, jj, hbuf[jj & 1]) != 0)
+            return set_err(BMM_E_CALLBACK, "relabel hook on_sample stopped the run at sweep %d", jj);
+        return BMM_OK;
+    };
+    for (int j = 1; j < nsamples; ++j) {
+        const bool window = j >= first_window && j < burnin;
+        const bool keep = j >= burnin && h->on_sample;
+        if (window && use_ring) c->probs_dst = ring.as<double>() + (size_t)(j - first_window) * mat;
+        else if (window || keep) c->probs_dst = dbuf[j & 1].as<double>();
+        else c->probs_dst = nullptr;
+        rc = bmm_chain_sweeps(c, 1);
+        const bool staged = c->probs_dst && !(window && use_ring);
+        c->probs_dst = nullptr;
+        if (rc) return rc;
+        if (staged) {
+            HIP_TRY(hipMemcpyAsync(hbuf[j & 1], dbuf[j & 1].p, mat_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(ev[j & 1], c->stream));
+        }
+        if (pending >= 0) { rc = deliver(pending); pending = -1; if (rc) return rc; }
+        if (staged) pending = j;
+        if (j == burnin - 1) {  // collapsed_gibbs.cpp:188-190
+            if (pending >= 0) { rc = deliver(pending); pending = -1; if (rc) return rc; }
+            if (use_ring) {  // slices of sweeps j < 1 arrive as the zeros the ring was filled with
+                HIP_TRY(hipMemcpyAsync(h->probs_batch, ring.p, mat_bytes * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            if (h->batch_done && h->batch_done(h->user, j, h->probs_batch) != 0)
+                return set_err(BMM_E_CALLBACK, "relabel hook batch_done stopped the run");
+        }
+    }
+    if (pending >= 0) { rc = deliver(pending); if (rc) return rc; }
+    return BMM_OK;
+}
+
+// everything after the data are in place: starting state, the sweeps, the traces out
+int run_body(bmm_chain* c, int nsamples, const RunIO& io, const bmm_relabel_hooks* hooks) {
+    const int sampler = c->p.mode, K = c->p.K, P = c->p.P, S = c->S, burnin = c->burnin;
+    const int64_t N = c->p.N;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = BMM_OK;
+    if (sampler == BMM_SAMPLER_COLLAPSED) rc = bmm_chain_set_initial_labels(c, io.z0);
+    if (explicit_params(sampler)) rc = bmm_chain_set_initial_params(c, io.pi0, io.theta0);
     if (rc) return rc;
     if (burnin == 0) {
         // trace row 0 (DESIGN.md "Quirks"): labels = initial allocation or unassigned (-1 -> NA),
         // theta = NaN (collapsed, never written), 0 (dp, zero-filled) or the initial theta (sb)
         std::vector<double> t0((size_t)K * P, sampler == BMM_SAMPLER_DP ? 0.0 : std::nan(""));
-        if (explicit_params(sampler)) std::memcpy(t0.data(), theta0, t0.size() * sizeof(double));
+        if (explicit_params(sampler)) std::memcpy(t0.data(), io.theta0, t0.size() * sizeof(double));
         HIP_TRY(hipMemcpy(c->dThetaTrace, t0.data(), t0.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->dAlphaTrace, &c->alpha0, sizeof(double), hipMemcpyHostToDevice));
         if (explicit_params(sampler))
-            HIP_TRY(hipMemcpy2D(c->dPiTrace, (size_t)S * sizeof(double), pi0, sizeof(double), sizeof(double), K, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy2D(c->dPiTrace, (size_t)S * sizeof(double), io.pi0, sizeof(double), sizeof(double), K, hipMemcpyHostToDevice));
         if (sampler != BMM_SAMPLER_COLLAPSED) HIP_TRY(hipMemset(c->dTrace, 0xff, (size_t)N * sizeof(int32_t)));
     }
-    rc = bmm_chain_sweeps(c, nsamples - 1);
+    rc = hooks ? run_sweeps_hooked(c, nsamples, hooks) : bmm_chain_sweeps(c, nsamples - 1);
     if (rc) return rc;
     // labels: [S][N] 0-based -> S x N column-major 1-based, on the device, then one copy out
-    int32_t* dOut = nullptr;
-    HIP_TRY(hipMalloc(&dOut, (size_t)S * N * sizeof(int32_t)));
-    struct Free { void* p; ~Free() { (void)hipFree(p); } } fo{dOut};
+    DevBuf out;
+    HIP_TRY(out.alloc((size_t)S * N * sizeof(int32_t)));
     hipLaunchKernelGGL(k_trace_to_r, dim3((unsigned)((N + 31) / 32), (unsigned)((S + 31) / 32)), dim3(256), 0,
-                       c->stream, c->dTrace, N, S, dOut);
+                       c->stream, c->dTrace, N, S, out.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(z_out, dOut, (size_t)S * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(theta_out, c->dThetaTrace, (size_t)S * K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(alpha_out, c->dAlphaTrace, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(io.z_out, out.p, (size_t)S * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(io.theta_out, c->dThetaTrace, (size_t)S * K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(io.alpha_out, c->dAlphaTrace, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (explicit_params(sampler))
-        HIP_TRY(hipMemcpyAsync(pi_out, c->dPiTrace, (size_t)S * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(io.pi_out, c->dPiTrace, (size_t)S * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMM_OK;
+}
+
+int check_run_args(const int32_t* X, int nsamples, int burnin, const RunIO& io, int sampler) {
+    if (!X || !io.z_out || !io.theta_out || !io.alpha_out) return set_err(BMM_E_ARG, "null buffer");
+    if (sampler == BMM_SAMPLER_COLLAPSED && !io.z0) return set_err(BMM_E_ARG, "initialK is null");
+    if (explicit_params(sampler) && (!io.pi0 || !io.theta0 || !io.pi_out)) return set_err(BMM_E_ARG, "null buffer");
+    if (nsamples < 1) return set_err(BMM_E_ARG, "nsamples must be >= 1");
+    if (burnin < 0 || burnin >= nsamples) return set_err(BMM_E_ARG, "burnin must be in [0, nsamples)");
+    return BMM_OK;
+}
+
+int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int K, double alpha, double beta,
+              double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed, int device,
+              const RunIO& io, const bmm_relabel_hooks* hooks) {
+    int rc = check_run_args(X, nsamples, burnin, io, sampler);
+    if (rc) return rc;
+    bmm_chain* c = nullptr;
+    rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
+    if (rc) return rc;
+    struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
+    rc = run_prepare(c, nsamples, burnin);
+    if (rc) return rc;
+    rc = bmm_chain_set_data_host(c, X);
+    if (rc) return rc;
+    return run_body(c, nsamples, io, hooks);
+}
+
+// ---- RCCL, opened on demand: only a run that spans devices needs it, and a process that has
+// torch loaded must end up with one copy of the library (dlopen by soname finds a loaded one)
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+int rccl_open(Rccl& r) {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return set_err(BMM_E_RCCL, "RCCL is needed to broadcast the data across devices and could not be opened: %s", dlerror());
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.Broadcast || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+        return set_err(BMM_E_RCCL, "the RCCL library lacks an expected symbol");
+    return BMM_OK;
+}
+
+// One broadcast of `count` 32-bit words from bufs[0] (on devs[0]) into bufs[r] on devs[r], over a
+// communicator built in this process (ncclCommInitAll): the only collective of the chain path.
+int rccl_broadcast_words(const std::vector<int>& devs, const std::vector<void*>& bufs, size_t count) {
+    const int n = (int)devs.size();
+    if (n < 2) return BMM_OK;
+    Rccl r;
+    int rc = rccl_open(r);
+    if (rc) return rc;
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    ncclResult_t e = r.CommInitAll(comms.data(), n, devs.data());
+    if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclCommInitAll failed: %s", r.GetErrorString(e));
+    std::vector<hipStream_t> st((size_t)n, nullptr);
+    hipError_t he = hipSuccess;
+    for (int q = 0; q < n && he == hipSuccess; ++q) {
+        he = hipSetDevice(devs[(size_t)q]);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&st[(size_t)q], hipStreamNonBlocking);
+    }
+    if (he == hipSuccess) {
+        e = r.GroupStart();
+        for (int q = 0; q < n && e == ncclSuccess; ++q)
+            e = r.Broadcast(bufs[0], bufs[(size_t)q], count, ncclUint32, 0, comms[(size_t)q], st[(size_t)q]);
+        const ncclResult_t e2 = r.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        for (int q = 0; q < n && he == hipSuccess; ++q) {
+            he = hipSetDevice(devs[(size_t)q]);
+            if (he == hipSuccess) he = hipStreamSynchronize(st[(size_t)q]);
+        }
+    }
+    for (int q = 0; q < n; ++q) {
+        if (st[(size_t)q]) { (void)hipSetDevice(devs[(size_t)q]); (void)hipStreamDestroy(st[(size_t)q]); }
+        if (comms[(size_t)q]) (void)r.CommDestroy(comms[(size_t)q]);
+    }
+    if (he != hipSuccess) return set_err(BMM_E_HIP, "broadcasting the data failed: %s", hipGetErrorString(he));
+    if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclBroadcast failed: %s", r.GetErrorString(e));
     return BMM_OK;
 }
 
@@ -980,53 +1278,234 @@ int bmm_collapsed_run(const int32_t* X, int64_t N, int P, const int32_t* initial
                       double alpha, double beta, double gamma, double a, double b, int burnin,
                       int64_t batch, uint64_t seed, int device, int32_t* z_out, double* theta_out,
                       double* alpha_out) {
-    if (!initialK) return set_err(BMM_E_ARG, "initialK is null");
-    return run_chain(BMM_SAMPLER_COLLAPSED, X, N, P, initialK, nullptr, nullptr, nsamples, K, alpha, beta,
-                     gamma, a, b, burnin, batch, seed, device, nullptr, z_out, theta_out, alpha_out);
+    return bmm_collapsed_run_probs(X, N, P, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin, batch, seed,
+                                   device, z_out, theta_out, alpha_out, nullptr);
+}
+int bmm_collapsed_run_probs(const int32_t* X, int64_t N, int P, const int32_t* initialK, int nsamples, int K,
+                            double alpha, double beta, double gamma, double a, double b, int burnin,
+                            int64_t batch, uint64_t seed, int device, int32_t* z_out, double* theta_out,
+                            double* alpha_out, const bmm_relabel_hooks* hooks) {
+    RunIO io; io.z0 = initialK; io.z_out = z_out; io.theta_out = theta_out; io.alpha_out = alpha_out;
+    return run_chain(BMM_SAMPLER_COLLAPSED, X, N, P, nsamples, K, alpha, beta, gamma, a, b, burnin, batch, seed,
+                     device, io, hooks);
 }
 
 int bmm_dp_run(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta, double gamma,
                double a, double b, int burnin, int maxK, int64_t batch, uint64_t seed, int device,
                int32_t* z_out, double* theta_out, double* alpha_out) {
-    return run_chain(BMM_SAMPLER_DP, X, N, P, nullptr, nullptr, nullptr, nsamples, maxK, alpha, beta, gamma,
-                     a, b, burnin, batch, seed, device, nullptr, z_out, theta_out, alpha_out);
+    return bmm_dp_run_probs(X, N, P, nsamples, alpha, beta, gamma, a, b, burnin, maxK, batch, seed, device, z_out,
+                            theta_out, alpha_out, nullptr);
+}
+int bmm_dp_run_probs(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta, double gamma,
+                     double a, double b, int burnin, int maxK, int64_t batch, uint64_t seed, int device,
+                     int32_t* z_out, double* theta_out, double* alpha_out, const bmm_relabel_hooks* hooks) {
+    RunIO io; io.z_out = z_out; io.theta_out = theta_out; io.alpha_out = alpha_out;
+    return run_chain(BMM_SAMPLER_DP, X, N, P, nsamples, maxK, alpha, beta, gamma, a, b, burnin, batch, seed, device,
+                     io, hooks);
 }
 
 int bmm_sb_run(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
                int nsamples, int maxK, double alpha, double beta, double gamma, double a, double b,
                int burnin, uint64_t seed, int device, double* pi_out, int32_t* z_out, double* theta_out,
                double* alpha_out) {
-    if (!initialPi || !initialTheta || !pi_out) return set_err(BMM_E_ARG, "null buffer");
-    return run_chain(BMM_SAMPLER_SB, X, N, P, nullptr, initialPi, initialTheta, nsamples, maxK, alpha, beta,
-                     gamma, a, b, burnin, 0, seed, device, pi_out, z_out, theta_out, alpha_out);
+    return bmm_sb_run_probs(X, N, P, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
+                            seed, device, pi_out, z_out, theta_out, alpha_out, nullptr);
+}
+int bmm_sb_run_probs(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
+                     int nsamples, int maxK, double alpha, double beta, double gamma, double a, double b,
+                     int burnin, uint64_t seed, int device, double* pi_out, int32_t* z_out, double* theta_out,
+                     double* alpha_out, const bmm_relabel_hooks* hooks) {
+    RunIO io; io.pi0 = initialPi; io.theta0 = initialTheta; io.pi_out = pi_out; io.z_out = z_out;
+    io.theta_out = theta_out; io.alpha_out = alpha_out;
+    return run_chain(BMM_SAMPLER_SB, X, N, P, nsamples, maxK, alpha, beta, gamma, a, b, burnin, 0, seed, device, io,
+                     hooks);
 }
 
 int bmm_full_run(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
                  int nsamples, int K, double alpha, double beta, double gamma, double a, double b, int burnin,
                  uint64_t seed, int device, double* pi_out, int32_t* z_out, double* theta_out,
                  double* alpha_out) {
-    if (!initialPi || !initialTheta || !pi_out) return set_err(BMM_E_ARG, "null buffer");
-    return run_chain(BMM_SAMPLER_FULL, X, N, P, nullptr, initialPi, initialTheta, nsamples, K, alpha, beta,
-                     gamma, a, b, burnin, 0, seed, device, pi_out, z_out, theta_out, alpha_out);
+    return bmm_full_run_probs(X, N, P, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin, seed,
+                              device, pi_out, z_out, theta_out, alpha_out, nullptr);
+}
+int bmm_full_run_probs(const int32_t* X, int64_t N, int P, const double* initialPi, const double* initialTheta,
+                       int nsamples, int K, double alpha, double beta, double gamma, double a, double b,
+                       int burnin, uint64_t seed, int device, double* pi_out, int32_t* z_out,
+                       double* theta_out, double* alpha_out, const bmm_relabel_hooks* hooks) {
+    RunIO io; io.pi0 = initialPi; io.theta0 = initialTheta; io.pi_out = pi_out; io.z_out = z_out;
+    io.theta_out = theta_out; io.alpha_out = alpha_out;
+    return run_chain(BMM_SAMPLER_FULL, X, N, P, nsamples, K, alpha, beta, gamma, a, b, burnin, 0, seed, device, io,
+                     hooks);
+}
+
+// ---- several independent chains in one call (SURVEY.md section 8 rows b, e) ----------------
+int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* X, int64_t N, int P,
+                  const int32_t* const* initialK, const double* const* initialPi,
+                  const double* const* initialTheta, int nsamples, int K, double alpha, double beta,
+                  double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed,
+                  double* const* pi_out, int32_t* const* z_out, double* const* theta_out,
+                  double* const* alpha_out) {
+    if (sampler < 0 || sampler > 3) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
+    if (n_chains < 1) return set_err(BMM_E_ARG, "n_chains must be >= 1");
+    if (!z_out || !theta_out || !alpha_out) return set_err(BMM_E_ARG, "null output table");
+    if (sampler == BMM_SAMPLER_COLLAPSED && !initialK) return set_err(BMM_E_ARG, "initialK is null");
+    if (explicit_params(sampler) && (!initialPi || !initialTheta || !pi_out)) return set_err(BMM_E_ARG, "null buffer table");
+    std::vector<RunIO> io((size_t)n_chains);
+    for (int c = 0; c < n_chains; ++c) {
+        RunIO& q = io[(size_t)c];
+        if (sampler == BMM_SAMPLER_COLLAPSED) q.z0 = initialK[c];
+        if (explicit_params(sampler)) { q.pi0 = initialPi[c]; q.theta0 = initialTheta[c]; q.pi_out = pi_out[c]; }
+        q.z_out = z_out[c]; q.theta_out = theta_out[c]; q.alpha_out = alpha_out[c];
+        int rc = check_run_args(X, nsamples, burnin, q, sampler);
+        if (rc) return rc;
+    }
+    // chain c lives on devices[c] (device 0 when the table is null); distinct devices in first-use order
+    std::vector<int> dev_of((size_t)n_chains), devs;
+    for (int c = 0; c < n_chains; ++c) {
+        const int d = devices ? devices[c] : 0;
+        dev_of[(size_t)c] = d;
+        bool seen = false;
+        for (int e : devs) seen = seen || e == d;
+        if (!seen) devs.push_back(d);
+    }
+    std::vector<bmm_chain*> chains((size_t)n_chains, nullptr);
+    struct Guard {
+        std::vector<bmm_chain*>& v;
+        // borrowers first: a chain that lent its planes must outlive them
+        ~Guard() { for (bmm_chain* c : v) if (c && c->xb_borrowed) bmm_chain_destroy(c);
+                   for (bmm_chain* c : v) if (c && !c->xb_borrowed) bmm_chain_destroy(c); }
+    } guard{chains};
+    int rc = BMM_OK;
+    for (int c = 0; c < n_chains && rc == BMM_OK; ++c) {
+        rc = bmm_chain_create(&chains[(size_t)c], sampler, N, P, K, alpha, beta, gamma, a, b, batch,
+                              seed + (uint64_t)c, dev_of[(size_t)c]);
+        if (rc == BMM_OK) rc = run_prepare(chains[(size_t)c], nsamples, burnin);
+    }
+    if (rc) return rc;
+    // the data: uploaded and packed once, on the first chain's device; the bit planes (not the int32
+    // matrix: 160 MB instead of 4 GB at K=20, N=1e7, P=100) broadcast once to the other devices
+    std::vector<bmm_chain*> holder(devs.size(), nullptr);  // first chain of each device: owns its planes
+    for (size_t q = 0; q < devs.size(); ++q)
+        for (int c = 0; c < n_chains && !holder[q]; ++c)
+            if (dev_of[(size_t)c] == devs[q]) holder[q] = chains[(size_t)c];
+    rc = bmm_chain_set_data_host(holder[0], X);
+    if (rc) return rc;
+    if (devs.size() > 1) {
+        if (!holder[0]->bits) return set_err(BMM_E_UNSUPPORTED, "a run over several devices broadcasts bit planes");
+        std::vector<void*> bufs(devs.size(), nullptr);
+        int64_t words = 0;
+        for (size_t q = 0; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes(holder[q], &bufs[q], &words);
+        if (rc == BMM_OK) rc = rccl_broadcast_words(devs, bufs, (size_t)words);
+        for (size_t q = 1; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes_filled(holder[q]);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < n_chains; ++c) {
+        bmm_chain* ch = chains[(size_t)c];
+        if (ch->have_data) continue;
+        for (size_t q = 0; q < devs.size(); ++q)
+            if (devs[q] == dev_of[(size_t)c]) rc = bmm_chain_share_data(ch, holder[q]);
+        if (rc) return rc;
+    }
+    // one host thread per chain; each enqueues on its own stream, so chains on one device overlap
+    std::vector<int> status((size_t)n_chains, BMM_OK);
+    std::vector<std::string> msg((size_t)n_chains);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_chains; ++c)
+        th.emplace_back([&, c]() {
+            status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
+            if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+        });
+    for (std::thread& t : th) t.join();
+    for (int c = 0; c < n_chains; ++c)
+        if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
+    return BMM_OK;
+}
+
+// n resident chains advanced by `sweeps` sweeps each, one host thread per chain (launches of chains
+// that share a device overlap on their streams).  Returns without waiting for the GPU, as bmm_chain_sweeps.
+int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int sweeps) {
+    if (!chains || n_chains < 1) return set_err(BMM_E_ARG, "no chains");
+    if (n_chains == 1) return bmm_chain_sweeps(chains[0], sweeps);
+    std::vector<int> status((size_t)n_chains, BMM_OK);
+    std::vector<std::string> msg((size_t)n_chains);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_chains; ++c)
+        th.emplace_back([&, c]() {
+            status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
+            if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+        });
+    for (std::thread& t : th) t.join();
+    for (int c = 0; c < n_chains; ++c)
+        if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
+    return BMM_OK;
+}
+
+// The broadcast of bmm_multi_run on a pattern: fills `words` 32-bit words on devices[0], broadcasts them
+// to every listed device through RCCL (also with a single device: the library is opened, a
+// communicator built and the collective run) and compares.  What a box without several GPUs can check.
+int bmm_multi_selfcheck(int n_devices, const int* devices, int64_t words) {
+    if (n_devices < 1 || !devices || words < 1) return set_err(BMM_E_ARG, "bad argument");
+    std::vector<int> devs(devices, devices + n_devices);
+    for (int q = 0; q < n_devices; ++q)
+        for (int r2 = 0; r2 < q; ++r2)
+            if (devs[(size_t)q] == devs[(size_t)r2]) return set_err(BMM_E_ARG, "devices must be distinct");
+    std::vector<uint32_t> pat((size_t)words), got((size_t)words);
+    for (int64_t i = 0; i < words; ++i) pat[(size_t)i] = (uint32_t)i * 2654435761u + 12345u;
+    std::vector<DevBuf> bufs((size_t)n_devices);
+    std::vector<void*> ptrs((size_t)n_devices);
+    for (int q = 0; q < n_devices; ++q) {
+        HIP_TRY(hipSetDevice(devs[(size_t)q]));
+        HIP_TRY(bufs[(size_t)q].alloc((size_t)words * 4));
+        ptrs[(size_t)q] = bufs[(size_t)q].p;
+        if (q == 0) HIP_TRY(hipMemcpy(ptrs[0], pat.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(ptrs[(size_t)q], 0, (size_t)words * 4));
+    }
+    if (n_devices == 1) {  // rccl_broadcast_words skips a single device; here the collective itself is the point
+        Rccl r;
+        int rc = rccl_open(r);
+        if (rc) return rc;
+        ncclComm_t comm = nullptr;
+        ncclResult_t e = r.CommInitAll(&comm, 1, devs.data());
+        if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclCommInitAll failed: %s", r.GetErrorString(e));
+        hipStream_t st = nullptr;
+        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (he == hipSuccess) {
+            e = r.Broadcast(ptrs[0], ptrs[0], (size_t)words, ncclUint32, 0, comm, st);
+            he = hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+        (void)r.CommDestroy(comm);
+        if (he != hipSuccess) return set_err(BMM_E_HIP, "self-check stream failed: %s", hipGetErrorString(he));
+        if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclBroadcast failed: %s", r.GetErrorString(e));
+    } else {
+        int rc = rccl_broadcast_words(devs, ptrs, (size_t)words);
+        if (rc) return rc;
+    }
+    for (int q = 0; q < n_devices; ++q) {
+        HIP_TRY(hipSetDevice(devs[(size_t)q]));
+        HIP_TRY(hipMemcpy(got.data(), ptrs[(size_t)q], (size_t)words * 4, hipMemcpyDeviceToHost));
+        if (std::memcmp(got.data(), pat.data(), (size_t)words * 4) != 0)
+            return set_err(BMM_E_RCCL, "device %d holds different words after the broadcast", devs[(size_t)q]);
+    }
+    return BMM_OK;
 }
 
 int bmm_device_math(int device, int op, const double* in, const double* in2, double* out, int64_t n) {
-    if (!in || !out || n < 0 || op < 0 || op > 3) return set_err(BMM_E_ARG, "bad argument");
+    if (!in || !out || n < 0 || op < 0 || op > 4) return set_err(BMM_E_ARG, "bad argument");
     if (op == 2 && !in2) return set_err(BMM_E_ARG, "division needs in2");
     HIP_TRY(hipSetDevice(device));
-    double *di = nullptr, *di2 = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&di, n * sizeof(double)));
-    HIP_TRY(hipMalloc(&dout, n * sizeof(double)));
-    HIP_TRY(hipMemcpy(di, in, n * sizeof(double), hipMemcpyHostToDevice));
+    DevBuf bi, bi2, bo;
+    HIP_TRY(bi.alloc(n * sizeof(double)));
+    HIP_TRY(bo.alloc(n * sizeof(double)));
+    HIP_TRY(hipMemcpy(bi.p, in, n * sizeof(double), hipMemcpyHostToDevice));
     if (in2) {
-        HIP_TRY(hipMalloc(&di2, n * sizeof(double)));
-        HIP_TRY(hipMemcpy(di2, in2, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(bi2.alloc(n * sizeof(double)));
+        HIP_TRY(hipMemcpy(bi2.p, in2, n * sizeof(double), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, di, di2, dout, n);
+    hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, bi.as<double>(),
+                       bi2.as<double>(), bo.as<double>(), n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(di); (void)hipFree(dout);
-    if (di2) (void)hipFree(di2);
+    HIP_TRY(hipMemcpy(out, bo.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return BMM_OK;
 }
 
@@ -1034,12 +1513,12 @@ int bmm_device_variates(int device, int kind, double p, double q, uint64_t seed,
                         int64_t n) {
     if (!out || n < 0 || kind < 0 || kind > 2) return set_err(BMM_E_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device));
-    double* dout = nullptr;
-    HIP_TRY(hipMalloc(&dout, n * sizeof(double)));
-    hipLaunchKernelGGL(k_test_variates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, kind, p, q, seed, sweep, dout, n);
+    DevBuf bo;
+    HIP_TRY(bo.alloc(n * sizeof(double)));
+    hipLaunchKernelGGL(k_test_variates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, kind, p, q, seed, sweep,
+                       bo.as<double>(), n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dout);
+    HIP_TRY(hipMemcpy(out, bo.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return BMM_OK;
 }
 

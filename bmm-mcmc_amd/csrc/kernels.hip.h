@@ -37,12 +37,14 @@ enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2, MODE_FULL = 3 };
 __host__ __device__ inline bool explicit_params(int mode) { return mode == MODE_SB || mode == MODE_FULL; }
 
 // Layout of the table image in global memory, in doubles:
-//   Tp  [G][KT][16]   group tables against the full statistics
-//   Cp  [KT]          prior / weight term per category
+//   Tp  [G][KT][16]   group tables against the full statistics; group 0 carries the category's
+//                     prior / weight term Cp, so a score is just the sum of G entries
+//   Cp  [KT]          that term on its own (kept for inspection; the kernels do not read it)
 //   Cm  [KT]          ... with the scored observation removed from its own cluster
 //   Nk  [KT] int32    (two per double slot, padded to an even number of doubles)
-//   E   [64]          2^(j/64), the table of the spec's exp_ (read per lane in the draw)
-//   Tm  [G][KT][16]   group tables with the observation's own contribution removed (not SB)
+//   E   [256]         2^(j/256), the table of the spec's expw_ (read per lane in the draw)
+//   Tm  [G][KT][16]   group tables with the observation's own contribution removed, Cm in group 0
+//                     (not SB)
 // A workgroup copies the head (Tp..Nk) into LDS, and Tm too when both fit in 160 KiB;
 // otherwise Tm is gathered from global memory (L2-resident, 1/K of the lookups).
 struct TableLayout {
@@ -52,7 +54,7 @@ struct TableLayout {
     __host__ __device__ int cm() const { return cp() + KT; }
     __host__ __device__ int nk() const { return cm() + KT; }
     __host__ __device__ int et() const { return nk() + (KT + 1) / 2 + (((KT + 1) / 2) & 1); }
-    __host__ __device__ int tm() const { return et() + 64; }
+    __host__ __device__ int tm() const { return et() + 256; }
     __host__ __device__ int head() const { return tm(); }
     __host__ __device__ int doubles() const { return tm() + (has_minus ? G * KT * kGroupM : 0); }
 };
@@ -96,12 +98,14 @@ __device__ __forceinline__ void delta_clear(int32_t* d, size_t idx, size_t strid
 // folds the pending integer deltas of its cluster into the statistics.
 // ---------------------------------------------------------------------------------
 // e1/e0 hold the `pc` features of one chunk; its `gc` groups start at global group g0
+// `c` is the category's constant term: it goes into the entries of global group 0
 __device__ __forceinline__ void write_group_tables(const double* e1, const double* e0, int pc, int g0, int gc,
-                                                   int KT, int k, double* T) {
+                                                   int KT, int k, double c, double* T) {
     for (int idx = threadIdx.x; idx < gc * kGroupM; idx += blockDim.x) {
         const int g = idx / kGroupM;
         const unsigned m = idx % kGroupM;
-        T[((size_t)(g0 + g) * KT + k) * kGroupM + m] = group_entry(e1, e0, g, pc, m);
+        const double t = group_entry(e1, e0, g, pc, m);
+        T[((size_t)(g0 + g) * KT + k) * kGroupM + m] = g0 + g == 0 ? c + t : t;
     }
 }
 
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
                                                       int32_t* __restrict__ dS,
                                                       const double* __restrict__ alpha_ptr,
                                                       double* __restrict__ tab) {
-    __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP];
+    __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP], cst[2];
     const int k = blockIdx.x;
     const TableLayout L{p.G, p.KT, 1};
     const int P = p.P;
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
         }
         tab[L.cp() + k] = cp;
         tab[L.cm() + k] = cm;
+        cst[0] = cp; cst[1] = cm;  // read after the first barrier below
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
     }
     for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
@@ -176,15 +181,15 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
             S[(size_t)k * P + d] = s;
             delta_clear(dS, (size_t)k * P + d, KP);
         }
-        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
-        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tm());
+        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst[0], tab + L.tp());
+        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst[1], tab + L.tm());
         __syncthreads();
     }
     if (is_label && threadIdx.x == 0) {  // every thread read the old pair before the barriers above
         Nk[k] = (int32_t)n;
         delta_clear(dNk, k, p.K);
     }
-    if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
+    if (k == 0 && threadIdx.x < 256) tab[L.et() + threadIdx.x] = exp256_table()[threadIdx.x];
 }
 
 // Stick-breaking: theta_kd ~ Beta(beta + V_kd, gamma + c_k - V_kd) (stickbreaking.cpp:217-229),
@@ -197,14 +202,15 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
                                                          double* __restrict__ tab) {
     // 256 threads: a Beta draw is X / (X + Y) of two gammas on their own streams, so threads 0-127 draw
     // X and log theta for feature d while threads 128-255 draw Y and log(1 - theta): half the latency
-    __shared__ double e1[kMaxP], e0[kMaxP], gam[2][kMaxP];
+    __shared__ double e1[kMaxP], e0[kMaxP], gam[2][kMaxP], cst;
     const int k = blockIdx.x;
     const TableLayout L{p.G, p.KT, 0};
     const int P = p.P, K = p.K;
     const bool is_label = k < K;
     const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
     if (threadIdx.x == 255) {  // the constants, ahead of its own feature (if P reaches 128)
-        tab[L.cp() + k] = is_label ? log_(pi[k]) : neg_inf();
+        cst = is_label ? log_(pi[k]) : neg_inf();  // read after the barriers below
+        tab[L.cp() + k] = cst;
         tab[L.cm() + k] = neg_inf();
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
     }
@@ -234,10 +240,10 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
             if (half == 0) e1[dl] = t; else e0[dl] = t;
         }
         __syncthreads();
-        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, tab + L.tp());
+        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst, tab + L.tp());
         __syncthreads();
     }
-    if (k == 0 && threadIdx.x < 64) tab[L.et() + threadIdx.x] = exp2_table()[threadIdx.x];
+    if (k == 0) tab[L.et() + threadIdx.x] = exp256_table()[threadIdx.x];  // 256 threads
 }
 
 // Stick-breaking: fold deltas, v_k ~ Beta(1 + c_k, alpha + sum_{l>k} c_l), pi by stick
@@ -383,7 +389,8 @@ struct ResampleArgs {
     int64_t lo, hi;        // batch [lo, hi)
     uint32_t sweep;
     int minus_in_lds;      // 1: the Tm tables were sized into LDS too
-    double* probs;         // generic kernel only: N x K column-major normalised probabilities, or null
+    double* wts;           // or null: this sweep also emits the draw's weights, wts[k * N + i] for the Kc
+    double* wtot;          //   categories in order, and their total wtot[i] (k_probs_finish normalises)
     unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
 };
 
@@ -610,7 +617,9 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #ifndef BMM_LOOKUP_PRIO
 #define BMM_LOOKUP_PRIO 2
 #endif
-template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1>
+// EMIT: the launch also writes the draw's weights and their total (a.wts, a.wtot) for the probability
+// hand-off to the host's relabelling; a twin instantiation, so that the plain kernel carries no branch.
+template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
     static_assert(SPLIT == 1 || (SPLIT == 2 && BITS && MINUS != 2 && KT % 2 == 0), "split form");
     constexpr int GPS = STG / kGroupW;  // lookup groups per stage
@@ -628,8 +637,6 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const volatile lds_f64* const Tp = (const volatile lds_f64*)(lds + L.tp());
     const lds_f64* const TmL = (const lds_f64*)(lds + L.tm());
     const double* const TmG = a.tab + L.tm();
-    const double* const Cp = lds + L.cp();
-    const double* const Cm = lds + L.cm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(lds + L.nk());
     const lds_f64* const ET = (const lds_f64*)(lds + L.et());
     int32_t* const hist = reinterpret_cast<int32_t*>(lds + lds_doubles);  // [K*P] then [K]
@@ -780,53 +787,47 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 if (!BITS && has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_pack += n_ - d_t; d_t = n_; })
             }
-            // scores; the observation's own cluster is scored without itself
-            const double cm_own = Cm[zoc];
+            // scores (the constant terms sit in group 0 of the tables); the observation's own
+            // cluster is scored without itself
             double m = neg_inf();
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                double sc = Cp[kb + k] + acc[k];
-                if (has_minus && kb + k == zo) sc = cm_own + acc_own;
+                double sc = acc[k];
+                if (has_minus && kb + k == zo) sc = acc_own;
                 acc[k] = sc;
                 m = __builtin_fmax(m, sc);  // v_max_f64; scores are never NaN
             }
             if (SPLIT == 2) m = __builtin_fmax(m, __shfl_xor(m, 32));
-            double tot = 0.0;
+            // weights exp(score - max) and their running sum in label order; acc[k] becomes the CDF
+            double run = 0.0;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                const double w = exp_nonpos_tab(acc[k] - m, ET);
-                acc[k] = w;
-                tot = tot + w;
+                const double w = expw_tab(acc[k] - m, ET);
+                if (EMIT && kb + k < p.Kc && pos.valid) a.wts[(int64_t)(kb + k) * p.N + pos.i] = w;
+                if (SPLIT == 1) { run = run + w; acc[k] = run; }
+                else acc[k] = w;
                 if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two at a time: bounds the temporaries
             }
-            double cdf = 0.0;
             if (SPLIT == 2) {
                 // the running sum goes through the categories in label order: the upper half continues
                 // from the lower half's total
-                const double lower = __shfl(tot, lane & 31);
-                double run = lower;
 #pragma unroll
                 for (int k = 0; k < KH; ++k) run = run + acc[k];
-                tot = __shfl(run, (lane & 31) + 32);
-                cdf = half ? lower : 0.0;
+                const double lower = __shfl(run, lane & 31);
+                run = half ? lower : 0.0;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) { run = run + acc[k]; acc[k] = run; }
+                run = __shfl(run, (lane & 31) + 32);
             }
-            const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + pos.ic), a.sweep);
-            const double t = u * tot;
+            const double tot = run;
+            if (EMIT && half == 0 && pos.valid) a.wtot[pos.i] = tot;
+            // u <= 1 - 2^-52, so u * tot < tot: the walk always ends on a category with weight
+            const double t = z_uniform(p.seed, (uint64_t)(p.obs0 + pos.ic), a.sweep) * tot;
             int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < KH; ++k) {
-                cdf = cdf + acc[k];
-                cnt += t >= cdf ? 1 : 0;
-            }
+            for (int k = 0; k < KH; ++k) cnt += t >= acc[k] ? 1 : 0;
             if (SPLIT == 2) cnt += __shfl_xor(cnt, 32);
             int zn = cnt;
-            if (__any(cnt >= KT)) {  // u * tot rounded up to tot: the last category with weight
-                int last = -1;
-#pragma unroll
-                for (int k = 0; k < KH; ++k) last = acc[k] > 0.0 ? kb + k : last;
-                if (SPLIT == 2) { const int o = __shfl_xor(last, 32); last = o > last ? o : last; }
-                zn = cnt < KT ? cnt : last;
-            }
             if (!(m > neg_inf())) zn = zoc;  // every category impossible: keep (or 0)
             if (p.mode == MODE_DP && zn == K) {
                 const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 
 // ---------------------------------------------------------------------------------
 // Generic path: any P, up to kMaxCatsAny categories, no LDS residency.  Same arithmetic as
-// k_resample (group lookups in g order, C + sum, exp_nonpos, CDF walk in label order), with the
+// k_resample (group lookups in g order, expw_, running sum and count in label order), with the
 // tables gathered from global memory (L2) and the scores kept in a per-thread scratch column
 // scr[k * stride + thread].  Clusters are accumulated sixteen at a time, X is re-read per chunk.
 // Slow next to the resident kernel; it exists so that every shape the reference accepts runs.
@@ -899,8 +900,6 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
     const TableLayout L{p.G, p.KT, has_minus ? 1 : 0};
     const double* const Tp = a.tab + L.tp();
     const double* const Tm = a.tab + L.tm();
-    const double* const Cp = a.tab + L.cp();
-    const double* const Cm = a.tab + L.cm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(a.tab + L.nk());
     const double* const ET = a.tab + L.et();
     const int P = p.P, G = p.G, K = p.K, Kc = p.Kc, KT = p.KT;
@@ -936,38 +935,25 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
             for (int j = 0; j < 16; ++j) {
                 const int k = k0 + j;
                 if (k < Kc) {
-                    double sc = Cp[k] + acc[j];
-                    if (has_minus && k == zo) sc = Cm[zoc] + acc_own;
+                    double sc = acc[j];
+                    if (has_minus && k == zo) sc = acc_own;
                     my[(int64_t)k * stride] = sc;
                     m = __builtin_fmax(m, sc);
                 }
             }
         }
-        double tot = 0.0;
+        double run = 0.0;
         for (int k = 0; k < Kc; ++k) {
-            const double w = exp_nonpos_tab(my[(int64_t)k * stride] - m, ET);
-            my[(int64_t)k * stride] = w;
-            tot = tot + w;
+            const double w = expw_tab(my[(int64_t)k * stride] - m, ET);
+            if (a.wts) a.wts[(int64_t)k * p.N + i] = w;
+            run = run + w;
+            my[(int64_t)k * stride] = run;
         }
-        if (a.probs) {
-            // the matrix the host relabelling consumes (collapsed_gibbs.cpp:162-172): by label; the DP's
-            // new-cluster mass goes under the label it would open (collapsed_gibbs_dp.cpp:193)
-            for (int k = 0; k < Kc; ++k) {
-                const int lbl = k < K ? k : new_label;
-                if (lbl >= 0) a.probs[i + (int64_t)lbl * p.N] = div_(my[(int64_t)k * stride], tot);
-            }
-        }
-        const double u = z_uniform(p.seed, (uint64_t)(p.obs0 + i), a.sweep);
-        const double t = u * tot;
-        double cdf = 0.0;
-        int cnt = 0, last = -1;
-        for (int k = 0; k < Kc; ++k) {
-            const double w = my[(int64_t)k * stride];
-            cdf = cdf + w;
-            cnt += t >= cdf ? 1 : 0;
-            last = w > 0.0 ? k : last;
-        }
-        int zn = cnt < Kc ? cnt : last;
+        const double tot = run;
+        if (a.wts) a.wtot[i] = tot;
+        const double t = z_uniform(p.seed, (uint64_t)(p.obs0 + i), a.sweep) * tot;
+        int zn = 0;
+        for (int k = 0; k < Kc; ++k) zn += t >= my[(int64_t)k * stride] ? 1 : 0;
         if (!(m > neg_inf())) zn = zoc;
         if (p.mode == MODE_DP && zn == K) {
             const int own_single = (zo >= 0 && NkT[zoc] == 1) ? 1 : 0;
@@ -1012,6 +998,30 @@ __global__ __launch_bounds__(256) void k_count_labels_generic(ChainParams p, con
     }
 }
 
+// The allocation probabilities of one batch, normalised and filed by label: the matrix the reference
+// stores for Stephens' relabelling (collapsed_gibbs.cpp:162-172, collapsed_gibbs_dp.cpp:190-200,
+// stickbreaking.cpp:129-139).  wts/wtot are what the resample kernel of this batch emitted;
+// probs is N x K column-major.  The DP's new-cluster mass goes under the label it would open
+// (collapsed_gibbs_dp.cpp:193), read from the table image's cluster sizes of this batch.
+__global__ __launch_bounds__(256) void k_probs_finish(ChainParams p, const double* __restrict__ tab,
+                                                      const double* __restrict__ wts,
+                                                      const double* __restrict__ wtot, int64_t lo, int64_t hi,
+                                                      double* __restrict__ probs) {
+    const TableLayout L{p.G, p.KT, !explicit_params(p.mode) ? 1 : 0};
+    const int32_t* const NkT = reinterpret_cast<const int32_t*>(tab + L.nk());
+    int new_label = -1;
+    if (p.mode == MODE_DP)
+        for (int k = 0; k < p.K && new_label < 0; ++k)
+            if (NkT[k] <= 0) new_label = k;
+    for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
+        const double tot = wtot[i];
+        for (int k = 0; k < p.Kc; ++k) {
+            const int lbl = k < p.K ? k : new_label;
+            if (lbl >= 0) probs[i + (int64_t)lbl * p.N] = div_(wts[(int64_t)k * p.N + i], tot);
+        }
+    }
+}
+
 // S x N column-major 1-based output from the [S][N] 0-based device trace (tiled transpose)
 __global__ __launch_bounds__(256) void k_trace_to_r(const int32_t* __restrict__ trace, int64_t N, int S,
                                                     int32_t* __restrict__ out) {
@@ -1044,7 +1054,8 @@ __global__ void k_test_math(int op, const double* in, const double* in2, double*
     if (op == 0) y = log_(x);
     else if (op == 1) y = exp_(x);
     else if (op == 2) y = div_(x, in2[i]);
-    else y = sqrt_(x);
+    else if (op == 3) y = sqrt_(x);
+    else y = expw_(x);
     out[i] = y;
 }
 __global__ void k_test_variates(int kind, double pp, double qq, uint64_t seed, uint32_t sweep, double* out,

@@ -1,27 +1,46 @@
 /* bmmmcmc_shim.c -- .Call shim between R and the C ABI in include/bmm_mcmc.h.
  *
- * Plain C on R's own API (Rinternals.h); no Rcpp, no Armadillo.  It registers the
- * three hot entry points under exactly the names and arities the reference's
- * generated glue uses (/root/reference/src/RcppExports.cpp:137-146), with two extra
- * trailing arguments (seed, batch), so the package's R/RcppExports.R-style callers
- * keep working.  R is not installed in the build image, so this file is compiled
- * only where `R CMD SHLIB` exists:
+ * Plain C on R's own API (Rinternals.h); no Rcpp, no Armadillo.  It OWNS R_init_bmmmcmc and
+ * registers every .Call symbol of the package:
+ *
+ *   the four samplers under exactly the names and arities of the reference's generated glue
+ *   (/root/reference/src/RcppExports.cpp:137-146: collapsed 13, dp 12, gibbs_cpp 14,
+ *   stickbreaking 14), so the package's unchanged R/RcppExports.R binds: the chain's seed is
+ *   drawn inside, from R's RNG stream between GetRNGstate and PutRNGstate (set.seed() fixes the
+ *   chain, as RNGScope does in the reference, RcppExports.cpp:14), batch = library default, device 0;
+ *
+ *   the same four with trailing (seed, batch, chains, devices) under new names, *_ex, which this
+ *   build's R wrappers (../R/gibbs.R) call;
+ *
+ *   the three entry points this build does not touch (_bmmmcmc_rdirichlet_cpp 1, _bmmmcmc_my_lpsolve 1,
+ *   _bmmmcmc_my_stephens_batch 2; RcppExports.cpp:140,142,143): stand-alone they raise a clear R
+ *   error; with -DBMM_SHIM_FORWARD they are the package's own functions, linked in beside the shim
+ *   (INTEGRATION.md section 1 shows the two Makevars lines that rename the generated file's
+ *   R_init_bmmmcmc and its four sampler wrappers out of the way -- no source of the package is edited).
+ *
+ * R is not installed in the build image: tests/test_r_shim.py syntax-checks this file against a
+ * test-only declaration header of the R API symbols it uses and compares the registration table
+ * with the reference's.  Where R exists:
  *
  *   R CMD SHLIB -o bmmmcmc.so bmmmcmc_shim.c -I../../include -L../lib -lbmmmcmc_hip
  *
- * Ownership: inputs are R-owned and read-only; outputs are fresh R allocations
- * (PROTECTed here) whose raw pointers are handed to the C ABI, which fills them and
- * retains nothing.  Errors: the C ABI returns a status; this shim raises an R error
- * with bmm_last_error() after everything on the device has been released by the
- * callee.  No R API call is made off the main thread.
+ * Ownership: inputs are R-owned and read-only; outputs are fresh R allocations (PROTECTed here)
+ * whose raw pointers are handed to the C ABI, which fills them and retains nothing.  Errors: the
+ * C ABI returns a status; this shim raises an R error with bmm_last_error() after everything on
+ * the device has been released by the callee.  No R API call is made off the main thread
+ * (bmm_multi_run's worker threads never see a SEXP).
  */
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <R_ext/Random.h>
 #include <stdint.h>
 
 #include "bmm_mcmc.h"
 
+#define MAX_CHAINS 64
+
+/* ---------------------------------------------------------------- small helpers */
 static void need_int_matrix(SEXP df) {
     if (TYPEOF(df) != INTSXP || !isMatrix(df)) error("data must be an integer matrix");
 }
@@ -54,102 +73,253 @@ static SEXP cube(int a, int b, int c) {
 
 static void no_relabel(SEXP relabel) {
     if (asLogical(relabel) == TRUE)
-        error("relabel=TRUE stays on the reference's host path (stephens.cpp / my_lpsolve.cpp)");
+        error("relabel=TRUE feeds the package's own Stephens code (src/stephens.cpp) from "
+              "bmm_*_run_probs: build r-shim/relabel_glue.cpp into the package (INTEGRATION.md section 2)");
 }
 
-/* collapsed_gibbs_cpp(df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel,
- *                     burnrelabel, debug [, seed, batch]) */
+/* one 53-bit integer from R's stream: set.seed() determines the chain */
+static uint64_t seed_from_r(void) {
+    GetRNGstate();
+    const double u = unif_rand();
+    PutRNGstate();
+    return (uint64_t)(u * 9007199254740992.0);
+}
+
+/* seed argument of the *_ex entry points: NULL -> R's stream; else a whole number in [0, 2^53] */
+static uint64_t seed_arg(SEXP seed) {
+    if (seed == R_NilValue) return seed_from_r();
+    const double v = asReal(seed);
+    if (ISNAN(v) || v < 0.0 || v > 9007199254740992.0 || v != (double)(uint64_t)v)
+        error("seed must be a whole number in [0, 2^53] (or NULL to draw it from R's RNG)");
+    return (uint64_t)v;
+}
+
+static int64_t batch_arg(SEXP batch) {
+    if (batch == R_NilValue) return 0; /* library default */
+    const double v = asReal(batch);
+    if (ISNAN(v) || v < 0.0 || v > 9007199254740992.0) error("batch must be NULL or a non-negative number");
+    return (int64_t)v;
+}
+
+static int chains_arg(SEXP chains) {
+    const int n = chains == R_NilValue ? 1 : asInteger(chains);
+    if (n == NA_INTEGER || n < 1 || n > MAX_CHAINS) error("chains must be between 1 and %d", MAX_CHAINS);
+    return n;
+}
+
+/* devices: NULL (every chain on device 0) or one device per chain; returns dev (or NULL) */
+static const int* devices_arg(SEXP devices, int chains, int* dev) {
+    if (devices == R_NilValue) return NULL;
+    SEXP d = PROTECT(coerceVector(devices, INTSXP));
+    if (XLENGTH(d) != chains) { UNPROTECT(1); error("devices must name one device per chain"); }
+    for (int c = 0; c < chains; ++c) dev[c] = INTEGER(d)[c];
+    UNPROTECT(1);
+    return dev;
+}
+
+typedef struct {
+    int N, P, ns, K, bi, S;
+} dims_t;
+
+static dims_t dims_of(SEXP df, SEXP nsamples, SEXP K, SEXP burnin) {
+    need_int_matrix(df);
+    dims_t d;
+    d.N = nrows(df); d.P = ncols(df); d.ns = asInteger(nsamples); d.K = asInteger(K); d.bi = asInteger(burnin);
+    d.S = d.ns - d.bi;
+    if (d.ns == NA_INTEGER || d.K == NA_INTEGER || d.bi == NA_INTEGER) error("nsamples, K and burnin must be numbers");
+    if (d.S < 1) error("burnin must be smaller than nsamples");
+    return d;
+}
+
+/* ---------------------------------------------------------------- the counting samplers */
+/* sampler: BMM_SAMPLER_COLLAPSED (initialK: N x chains integer) or BMM_SAMPLER_DP (initialK unused) */
+static SEXP counting_run(int sampler, SEXP df, SEXP initialK, dims_t d, SEXP alpha, SEXP beta, SEXP gamma,
+                         SEXP a, SEXP b, uint64_t seed, int64_t batch, int chains, const int* dev) {
+    const int32_t* z0[MAX_CHAINS];
+    int32_t* zs[MAX_CHAINS];
+    double *ths[MAX_CHAINS], *als[MAX_CHAINS];
+    int nprot = 0;
+    SEXP z0s = R_NilValue;
+    if (sampler == BMM_SAMPLER_COLLAPSED) {
+        z0s = PROTECT(coerceVector(initialK, INTSXP)); ++nprot;
+        if (XLENGTH(z0s) != (R_xlen_t)d.N * chains) { UNPROTECT(nprot); error("initialK must hold one label per observation and chain"); }
+        for (int c = 0; c < chains; ++c) z0[c] = INTEGER(z0s) + (R_xlen_t)c * d.N;
+    }
+    SEXP out = PROTECT(allocVector(VECSXP, chains)); ++nprot;
+    const char* nm[] = {"alpha", "permutations", "z", "theta"};
+    for (int c = 0; c < chains; ++c) {
+        SEXP z = PROTECT(allocMatrix(INTSXP, d.S, d.N)), th = PROTECT(cube(d.K, d.P, d.S));
+        SEXP al = PROTECT(allocMatrix(REALSXP, d.S, 1)), pm = PROTECT(na_perm(d.S, d.K));
+        SEXP v[] = {al, pm, z, th};
+        SET_VECTOR_ELT(out, c, named_list(4, nm, v));
+        UNPROTECT(4);
+        zs[c] = INTEGER(z); ths[c] = REAL(th); als[c] = REAL(al);
+    }
+    int rc;
+    if (chains == 1 && sampler == BMM_SAMPLER_COLLAPSED)
+        rc = bmm_collapsed_run(INTEGER(df), d.N, d.P, z0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma),
+                               asReal(a), asReal(b), d.bi, batch, seed, dev ? dev[0] : 0, zs[0], ths[0], als[0]);
+    else if (chains == 1)
+        rc = bmm_dp_run(INTEGER(df), d.N, d.P, d.ns, asReal(alpha), asReal(beta), asReal(gamma), asReal(a), asReal(b),
+                        d.bi, d.K, batch, seed, dev ? dev[0] : 0, zs[0], ths[0], als[0]);
+    else
+        rc = bmm_multi_run(sampler, chains, dev, INTEGER(df), d.N, d.P, sampler == BMM_SAMPLER_COLLAPSED ? z0 : NULL,
+                           NULL, NULL, d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma), asReal(a), asReal(b),
+                           d.bi, batch, seed, NULL, zs, ths, als);
+    if (rc) { UNPROTECT(nprot); error("%s", bmm_last_error()); }
+    SEXP ret = chains == 1 ? VECTOR_ELT(out, 0) : out; /* one chain: the reference's list itself */
+    UNPROTECT(nprot);
+    return ret;
+}
+
+/* collapsed_gibbs_cpp(df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug)
+ * -- src/RcppExports.cpp:10, 13 arguments */
 SEXP _bmmmcmc_collapsed_gibbs_cpp(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta,
                                   SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
-                                  SEXP debug, SEXP seed, SEXP batch) {
-    need_int_matrix(df);
+                                  SEXP debug) {
     no_relabel(relabel);
-    const int N = nrows(df), P = ncols(df), ns = asInteger(nsamples), k = asInteger(K), bi = asInteger(burnin);
-    const int S = ns - bi;
-    if (S < 1) error("burnin must be smaller than nsamples");
-    SEXP z0 = PROTECT(coerceVector(initialK, INTSXP));
-    SEXP z = PROTECT(allocMatrix(INTSXP, S, N)), th = PROTECT(cube(k, P, S)), al = PROTECT(allocMatrix(REALSXP, S, 1));
-    const int rc = bmm_collapsed_run(INTEGER(df), N, P, INTEGER(z0), ns, k, asReal(alpha), asReal(beta),
-                                     asReal(gamma), asReal(a), asReal(b), bi, (int64_t)asReal(batch),
-                                     (uint64_t)asReal(seed), 0, INTEGER(z), REAL(th), REAL(al));
-    if (rc) { UNPROTECT(4); error("%s", bmm_last_error()); }
-    SEXP pm = PROTECT(na_perm(S, k));
-    const char* nm[] = {"alpha", "permutations", "z", "theta"};
-    SEXP v[] = {al, pm, z, th};
-    SEXP out = named_list(4, nm, v);
-    UNPROTECT(5);
-    return out;
+    return counting_run(BMM_SAMPLER_COLLAPSED, df, initialK, dims_of(df, nsamples, K, burnin), alpha, beta, gamma, a, b,
+                        seed_from_r(), 0, 1, NULL);
+}
+SEXP _bmmmcmc_collapsed_gibbs_ex(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta, SEXP gamma,
+                                 SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP debug,
+                                 SEXP seed, SEXP batch, SEXP chains, SEXP devices) {
+    no_relabel(relabel);
+    int dev[MAX_CHAINS];
+    const int n = chains_arg(chains);
+    return counting_run(BMM_SAMPLER_COLLAPSED, df, initialK, dims_of(df, nsamples, K, burnin), alpha, beta, gamma, a, b,
+                        seed_arg(seed), batch_arg(batch), n, devices_arg(devices, n, dev));
 }
 
-/* collapsed_gibbs_dp_cpp(df, nsamples, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel,
- *                        maxK, debug [, seed, batch]) */
+/* collapsed_gibbs_dp_cpp(df, nsamples, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, maxK, debug)
+ * -- src/RcppExports.cpp:33, 12 arguments */
 SEXP _bmmmcmc_collapsed_gibbs_dp_cpp(SEXP df, SEXP nsamples, SEXP alpha, SEXP beta, SEXP gamma, SEXP a,
                                      SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP maxK,
-                                     SEXP debug, SEXP seed, SEXP batch) {
-    need_int_matrix(df);
+                                     SEXP debug) {
     no_relabel(relabel);
-    const int N = nrows(df), P = ncols(df), ns = asInteger(nsamples), k = asInteger(maxK), bi = asInteger(burnin);
-    const int S = ns - bi;
-    if (S < 1) error("burnin must be smaller than nsamples");
-    SEXP z = PROTECT(allocMatrix(INTSXP, S, N)), th = PROTECT(cube(k, P, S)), al = PROTECT(allocMatrix(REALSXP, S, 1));
-    const int rc = bmm_dp_run(INTEGER(df), N, P, ns, asReal(alpha), asReal(beta), asReal(gamma), asReal(a),
-                              asReal(b), bi, k, (int64_t)asReal(batch), (uint64_t)asReal(seed), 0, INTEGER(z),
-                              REAL(th), REAL(al));
-    if (rc) { UNPROTECT(3); error("%s", bmm_last_error()); }
-    SEXP pm = PROTECT(na_perm(S, k));
-    const char* nm[] = {"alpha", "permutations", "z", "theta"};
-    SEXP v[] = {al, pm, z, th};
-    SEXP out = named_list(4, nm, v);
-    UNPROTECT(4);
-    return out;
+    return counting_run(BMM_SAMPLER_DP, df, R_NilValue, dims_of(df, nsamples, maxK, burnin), alpha, beta, gamma, a, b,
+                        seed_from_r(), 0, 1, NULL);
+}
+SEXP _bmmmcmc_collapsed_gibbs_dp_ex(SEXP df, SEXP nsamples, SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b,
+                                    SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP maxK, SEXP debug,
+                                    SEXP seed, SEXP batch, SEXP chains, SEXP devices) {
+    no_relabel(relabel);
+    int dev[MAX_CHAINS];
+    const int n = chains_arg(chains);
+    return counting_run(BMM_SAMPLER_DP, df, R_NilValue, dims_of(df, nsamples, maxK, burnin), alpha, beta, gamma, a, b,
+                        seed_arg(seed), batch_arg(batch), n, devices_arg(devices, n, dev));
 }
 
-/* gibbs_stickbreaking_cpp / gibbs_cpp (df, initialPi, initialTheta, nsamples, maxK or K, alpha, beta,
- *                         gamma, a, b, burnin, relabel, burnrelabel, debug [, seed]) */
-static SEXP explicit_params_run(int full, SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
-                                SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
-                                SEXP relabel, SEXP burnrelabel, SEXP debug, SEXP seed) {
-    need_int_matrix(df);
-    no_relabel(relabel);
-    const int N = nrows(df), P = ncols(df), ns = asInteger(nsamples), k = asInteger(maxK), bi = asInteger(burnin);
-    const int S = ns - bi;
-    if (S < 1) error("burnin must be smaller than nsamples");
-    SEXP pi0 = PROTECT(coerceVector(initialPi, REALSXP)), th0 = PROTECT(coerceVector(initialTheta, REALSXP));
-    if (XLENGTH(pi0) != k || XLENGTH(th0) != (R_xlen_t)k * P) { UNPROTECT(2); error("initialPi/initialTheta have the wrong size"); }
-    SEXP z = PROTECT(allocMatrix(INTSXP, S, N)), th = PROTECT(cube(k, P, S)), al = PROTECT(allocMatrix(REALSXP, S, 1));
-    SEXP pi = PROTECT(allocMatrix(REALSXP, S, k));
-    const int rc = (full ? bmm_full_run : bmm_sb_run)(INTEGER(df), N, P, REAL(pi0), REAL(th0), ns, k, asReal(alpha),
-                                                      asReal(beta), asReal(gamma), asReal(a), asReal(b), bi,
-                                                      (uint64_t)asReal(seed), 0, REAL(pi), INTEGER(z), REAL(th),
-                                                      REAL(al));
-    if (rc) { UNPROTECT(6); error("%s", bmm_last_error()); }
-    SEXP pm = PROTECT(na_perm(S, k));
+/* ---------------------------------------------------------------- the explicit-parameter samplers */
+/* initialPi: K x chains, initialTheta: (K*P) x chains (each column a K x P matrix, column-major) */
+static SEXP explicit_run(int sampler, SEXP df, SEXP initialPi, SEXP initialTheta, dims_t d, SEXP alpha, SEXP beta,
+                         SEXP gamma, SEXP a, SEXP b, uint64_t seed, int chains, const int* dev) {
+    const double *pi0[MAX_CHAINS], *th0[MAX_CHAINS];
+    int32_t* zs[MAX_CHAINS];
+    double *ths[MAX_CHAINS], *als[MAX_CHAINS], *pis[MAX_CHAINS];
+    int nprot = 0;
+    SEXP p0 = PROTECT(coerceVector(initialPi, REALSXP)), t0 = PROTECT(coerceVector(initialTheta, REALSXP));
+    nprot += 2;
+    const R_xlen_t kp = (R_xlen_t)d.K * d.P;
+    if (XLENGTH(p0) != (R_xlen_t)d.K * chains || XLENGTH(t0) != kp * chains) {
+        UNPROTECT(nprot);
+        error("initialPi/initialTheta have the wrong size");
+    }
+    for (int c = 0; c < chains; ++c) { pi0[c] = REAL(p0) + (R_xlen_t)c * d.K; th0[c] = REAL(t0) + c * kp; }
+    SEXP out = PROTECT(allocVector(VECSXP, chains)); ++nprot;
     const char* nm[] = {"pi", "alpha", "permutations", "z", "theta"};
-    SEXP v[] = {pi, al, pm, z, th};
-    SEXP out = named_list(5, nm, v);
-    UNPROTECT(7);
-    return out;
+    for (int c = 0; c < chains; ++c) {
+        SEXP z = PROTECT(allocMatrix(INTSXP, d.S, d.N)), th = PROTECT(cube(d.K, d.P, d.S));
+        SEXP al = PROTECT(allocMatrix(REALSXP, d.S, 1)), pi = PROTECT(allocMatrix(REALSXP, d.S, d.K));
+        SEXP pm = PROTECT(na_perm(d.S, d.K));
+        SEXP v[] = {pi, al, pm, z, th};
+        SET_VECTOR_ELT(out, c, named_list(5, nm, v));
+        UNPROTECT(5);
+        zs[c] = INTEGER(z); ths[c] = REAL(th); als[c] = REAL(al); pis[c] = REAL(pi);
+    }
+    int rc;
+    if (chains == 1)
+        rc = (sampler == BMM_SAMPLER_FULL ? bmm_full_run : bmm_sb_run)(
+            INTEGER(df), d.N, d.P, pi0[0], th0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma), asReal(a),
+            asReal(b), d.bi, seed, dev ? dev[0] : 0, pis[0], zs[0], ths[0], als[0]);
+    else
+        rc = bmm_multi_run(sampler, chains, dev, INTEGER(df), d.N, d.P, NULL, pi0, th0, d.ns, d.K, asReal(alpha),
+                           asReal(beta), asReal(gamma), asReal(a), asReal(b), d.bi, 0, seed, pis, zs, ths, als);
+    if (rc) { UNPROTECT(nprot); error("%s", bmm_last_error()); }
+    SEXP ret = chains == 1 ? VECTOR_ELT(out, 0) : out;
+    UNPROTECT(nprot);
+    return ret;
 }
 
+/* gibbs_stickbreaking_cpp(df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
+ * relabel, burnrelabel, debug) -- src/RcppExports.cpp:113, 14 arguments */
 SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
                                       SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
-                                      SEXP relabel, SEXP burnrelabel, SEXP debug, SEXP seed) {
-    return explicit_params_run(0, df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
-                               relabel, burnrelabel, debug, seed);
+                                      SEXP relabel, SEXP burnrelabel, SEXP debug) {
+    no_relabel(relabel);
+    return explicit_run(BMM_SAMPLER_SB, df, initialPi, initialTheta, dims_of(df, nsamples, maxK, burnin), alpha, beta,
+                        gamma, a, b, seed_from_r(), 1, NULL);
 }
-/* gibbs_cpp, src/full_gibbs.cpp:32 */
-SEXP _bmmmcmc_gibbs_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha,
-                        SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
-                        SEXP debug, SEXP seed) {
-    return explicit_params_run(1, df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin,
-                               relabel, burnrelabel, debug, seed);
+SEXP _bmmmcmc_gibbs_stickbreaking_ex(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
+                                     SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel,
+                                     SEXP burnrelabel, SEXP debug, SEXP seed, SEXP chains, SEXP devices) {
+    no_relabel(relabel);
+    int dev[MAX_CHAINS];
+    const int n = chains_arg(chains);
+    return explicit_run(BMM_SAMPLER_SB, df, initialPi, initialTheta, dims_of(df, nsamples, maxK, burnin), alpha, beta,
+                        gamma, a, b, seed_arg(seed), n, devices_arg(devices, n, dev));
 }
 
+/* gibbs_cpp(df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel,
+ * debug) -- src/RcppExports.cpp:65, 14 arguments */
+SEXP _bmmmcmc_gibbs_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha,
+                        SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
+                        SEXP debug) {
+    no_relabel(relabel);
+    return explicit_run(BMM_SAMPLER_FULL, df, initialPi, initialTheta, dims_of(df, nsamples, K, burnin), alpha, beta,
+                        gamma, a, b, seed_from_r(), 1, NULL);
+}
+SEXP _bmmmcmc_gibbs_ex(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta,
+                       SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP debug,
+                       SEXP seed, SEXP chains, SEXP devices) {
+    no_relabel(relabel);
+    int dev[MAX_CHAINS];
+    const int n = chains_arg(chains);
+    return explicit_run(BMM_SAMPLER_FULL, df, initialPi, initialTheta, dims_of(df, nsamples, K, burnin), alpha, beta,
+                        gamma, a, b, seed_arg(seed), n, devices_arg(devices, n, dev));
+}
+
+/* ---------------------------------------------------------------- the entry points this build does not touch */
+#ifdef BMM_SHIM_FORWARD
+/* the package's own functions (generated glue over src/full_gibbs.cpp:10, src/my_lpsolve.cpp:6,
+ * src/stephens.cpp:6), linked in beside the shim: registered as they are */
+extern SEXP _bmmmcmc_rdirichlet_cpp(SEXP alpha_m);
+extern SEXP _bmmmcmc_my_lpsolve(SEXP x);
+extern SEXP _bmmmcmc_my_stephens_batch(SEXP p, SEXP debug);
+#else
+static void stays_in_reference(const char* what) {
+    error("%s is host code of the bmmmcmc package that this GPU build leaves untouched; build the shim "
+          "with -DBMM_SHIM_FORWARD beside the package's own objects to keep it callable (INTEGRATION.md)", what);
+}
+SEXP _bmmmcmc_rdirichlet_cpp(SEXP alpha_m) { stays_in_reference("rdirichlet_cpp"); return R_NilValue; }
+SEXP _bmmmcmc_my_lpsolve(SEXP x) { stays_in_reference("my_lpsolve"); return R_NilValue; }
+SEXP _bmmmcmc_my_stephens_batch(SEXP p, SEXP debug) { stays_in_reference("my_stephens_batch"); return R_NilValue; }
+#endif
+
+/* The first seven rows are the reference's table, name for name and arity for arity
+ * (src/RcppExports.cpp:137-146); tests/test_r_shim.py holds them to it. */
 static const R_CallMethodDef CallEntries[] = {
-    {"_bmmmcmc_collapsed_gibbs_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_cpp, 15},
-    {"_bmmmcmc_collapsed_gibbs_dp_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_dp_cpp, 14},
-    {"_bmmmcmc_gibbs_stickbreaking_cpp", (DL_FUNC)&_bmmmcmc_gibbs_stickbreaking_cpp, 15},
-    {"_bmmmcmc_gibbs_cpp", (DL_FUNC)&_bmmmcmc_gibbs_cpp, 15},
+    {"_bmmmcmc_collapsed_gibbs_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_cpp, 13},
+    {"_bmmmcmc_collapsed_gibbs_dp_cpp", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_dp_cpp, 12},
+    {"_bmmmcmc_rdirichlet_cpp", (DL_FUNC)&_bmmmcmc_rdirichlet_cpp, 1},
+    {"_bmmmcmc_gibbs_cpp", (DL_FUNC)&_bmmmcmc_gibbs_cpp, 14},
+    {"_bmmmcmc_my_lpsolve", (DL_FUNC)&_bmmmcmc_my_lpsolve, 1},
+    {"_bmmmcmc_my_stephens_batch", (DL_FUNC)&_bmmmcmc_my_stephens_batch, 2},
+    {"_bmmmcmc_gibbs_stickbreaking_cpp", (DL_FUNC)&_bmmmcmc_gibbs_stickbreaking_cpp, 14},
+    {"_bmmmcmc_collapsed_gibbs_ex", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_ex, 17},
+    {"_bmmmcmc_collapsed_gibbs_dp_ex", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_dp_ex, 16},
+    {"_bmmmcmc_gibbs_ex", (DL_FUNC)&_bmmmcmc_gibbs_ex, 17},
+    {"_bmmmcmc_gibbs_stickbreaking_ex", (DL_FUNC)&_bmmmcmc_gibbs_stickbreaking_ex, 17},
     {NULL, NULL, 0}};
 
 void R_init_bmmmcmc(DllInfo* dll) {

@@ -19,9 +19,31 @@
  *
  * `batch`: observations are resampled in consecutive batches of this many against
  * sufficient statistics frozen at batch start, each with its own contribution
- * removed exactly.  batch = 1 is the reference's sequential scan; batch <= 0 picks the
- * library default.  `seed` keys the Philox4x32-10 streams; same seed + same batch
- * => same chain, on any device.
+ * removed exactly.  batch = 1 is the reference's sequential scan (src/collapsed_gibbs.cpp:86-182
+ * updates the member lists after every draw); batch <= 0 picks bmm_default_batch(sampler, N), a
+ * function of the sampler and N only.  `seed` keys the Philox streams; same seed + same batch
+ * (given or defaulted) => same chain, bit for bit, on any device and with either X layout.
+ *
+ * TOLERANCE of a batch > 1 against the sequential scan (the north star's "stated floating-point
+ * tolerance on posterior cluster proportions").  Quantity: the posterior-mean cluster
+ * proportions, sorted descending (label-switching invariant), averaged over the kept sweeps.
+ *   BMM_TOL_PROPORTIONS 0.015  |default-batch chain - batch-1 chain| per component, both averaged
+ *                              over >= 3 seeds, on each of the reference's bundled data sets
+ *                              (measured, 3 seeds x 400 kept sweeps: 0.0002 on K2_N100_P5, 0.0001 on
+ *                              K2_N1000_P5, 0.005 on K3_N1000_P5, whose two 0.2 components overlap)
+ *   BMM_TOL_THETA       0.05   the same comparison for theta-hat, per cell, clusters ordered by size
+ *                              within each sweep (measured 0.0004, 0.0001, 0.037).  Against the
+ *                              generating values the reference documents (R/bmm-mcmc.R:16-17, 34-35,
+ *                              49-50) theta-hat of K2_N1000_P5 is within the same 0.05 (measured
+ *                              0.035); on K3_N1000_P5 the posterior itself, at batch 1 as at the
+ *                              default, sits up to 0.16 from them (finite sample, overlapping
+ *                              components), so there the pin is the batch-1 chain, not the truth.
+ * The DP sampler at its default batch (N/16): the two dominant components of K2_N1000_P5 within 0.05
+ * of the batch-1 chain over 6 seeds (measured 0.038; noise-limited -- an unbounded-K chain wanders,
+ * seed s.d. 0.08).
+ * tests/test_gpu_tolerance.py holds the HIP path to all of it on the GPU, default batch against the
+ * batch-1 oracle chain.  The stick-breaking and full samplers have no batch and no tolerance:
+ * their z-step is exactly parallel (src/stickbreaking.cpp:69-92 reads only sweep j-1).
  */
 #ifndef BMM_MCMC_H
 #define BMM_MCMC_H
@@ -38,6 +60,11 @@ extern "C" {
 #define BMM_E_HIP 3         /* a HIP runtime call failed */
 #define BMM_E_NODEVICE 4    /* no usable gfx950 device */
 #define BMM_E_STATE 5       /* call sequence error on a resident chain */
+#define BMM_E_RCCL 6        /* RCCL could not be opened, or a collective failed */
+#define BMM_E_CALLBACK 7    /* a relabel hook returned non-zero */
+
+#define BMM_TOL_PROPORTIONS 0.015
+#define BMM_TOL_THETA 0.05
 
 #define BMM_SAMPLER_COLLAPSED 0
 #define BMM_SAMPLER_DP 1
@@ -50,7 +77,8 @@ const char* bmm_last_error(void);
 /* features per lookup group of the spec arithmetic (DESIGN.md "Numerics") */
 int bmm_spec_group_width(void);
 /* library default batch size for N observations (used when batch <= 0): N/8 for the finite
- * sampler, N/16 for the DP sampler, N for stick-breaking; see DESIGN.md "Batches" */
+ * sampler, N/16 for the DP sampler (rounded up to a multiple of 2^18 above that), N for
+ * stick-breaking and full; depends on nothing else.  See DESIGN.md "Batches" */
 int64_t bmm_default_batch(int sampler, int64_t N);
 
 /* ---- drop-in entry points --------------------------------------------------------
@@ -81,6 +109,69 @@ int bmm_full_run(const int32_t* X, int64_t N, int P, const double* initialPi,
                  double gamma, double a, double b, int burnin, uint64_t seed, int device,
                  double* pi_out, int32_t* z_out, double* theta_out, double* alpha_out);
 
+/* ---- relabel = TRUE: the per-sweep allocation probabilities for the host's Stephens code ----
+ * The reference stores, per observation, the normalised conditional it drew z_i from: for the last
+ * `burnrelabel` burn-in sweeps into the cube probs_out (N x K x burnrelabel,
+ * src/collapsed_gibbs.cpp:76,162-167) that my_stephens_batch consumes once at j = burnin - 1
+ * (:187-190), then every kept sweep's N x K matrix probs_sample for my_stephens_online (:168-172,
+ * :191-192).  Stephens' algorithm and lp_solve stay host code of the reference, unchanged; the
+ * *_run_probs entry points produce exactly those matrices on the device (from the resident
+ * resample kernel's own weights) and hand them over through these hooks, called on the calling
+ * thread.  Matrices are column-major, by label; the DP's new-cluster mass is filed under the label
+ * it would open (src/collapsed_gibbs_dp.cpp:193).  A hook returning non-zero stops the run
+ * (BMM_E_CALLBACK).  The chain itself does not depend on the relabelling, so sweep j + 1 already runs
+ * while on_sample works on sweep j.  hooks == NULL: exactly the plain *_run. */
+typedef int (*bmm_probs_fn)(void* user, int j /* sweep index, 1-based as the reference's loop */,
+                            const double* probs /* host, valid during the call */);
+typedef struct bmm_relabel_hooks {
+    int burnrelabel;         /* sweeps of the batch window (clamped to burnin) */
+    double* probs_batch;     /* N x K x burnrelabel doubles, filled before batch_done; caller-owned */
+    bmm_probs_fn batch_done; /* once, after sweep burnin - 1; probs = probs_batch; may be NULL */
+    bmm_probs_fn on_sample;  /* after every sweep j >= burnin; probs = that sweep's N x K; may be NULL */
+    void* user;
+} bmm_relabel_hooks;
+int bmm_collapsed_run_probs(const int32_t* X, int64_t N, int P, const int32_t* initialK, int nsamples,
+                            int K, double alpha, double beta, double gamma, double a, double b,
+                            int burnin, int64_t batch, uint64_t seed, int device, int32_t* z_out,
+                            double* theta_out, double* alpha_out, const bmm_relabel_hooks* hooks);
+int bmm_dp_run_probs(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta,
+                     double gamma, double a, double b, int burnin, int maxK, int64_t batch,
+                     uint64_t seed, int device, int32_t* z_out, double* theta_out, double* alpha_out,
+                     const bmm_relabel_hooks* hooks);
+int bmm_sb_run_probs(const int32_t* X, int64_t N, int P, const double* initialPi,
+                     const double* initialTheta, int nsamples, int maxK, double alpha, double beta,
+                     double gamma, double a, double b, int burnin, uint64_t seed, int device,
+                     double* pi_out, int32_t* z_out, double* theta_out, double* alpha_out,
+                     const bmm_relabel_hooks* hooks);
+int bmm_full_run_probs(const int32_t* X, int64_t N, int P, const double* initialPi,
+                       const double* initialTheta, int nsamples, int K, double alpha, double beta,
+                       double gamma, double a, double b, int burnin, uint64_t seed, int device,
+                       double* pi_out, int32_t* z_out, double* theta_out, double* alpha_out,
+                       const bmm_relabel_hooks* hooks);
+
+/* ---- several independent chains in one call (SURVEY.md section 8 rows b and e) ---------------
+ * n_chains chains of one sampler over the same data, chain c keyed seed + c and resident on
+ * devices[c] (all on device 0 when devices is NULL; a device may appear several times: its chains
+ * share one copy of the data and overlap on their own streams).  X is uploaded and packed into bit
+ * planes once, on devices[0]; when the run spans several devices the planes -- 4 * ceil(P/32) bytes
+ * per observation, not the int32 matrix -- are broadcast once with RCCL over xGMI inside this
+ * process (ncclCommInitAll over the distinct devices, one ncclBroadcast; librccl is opened on
+ * demand, BMM_E_RCCL if that fails).  That is the only collective: chains never communicate.
+ * One host thread per chain drives it; nothing of R's API is touched off the calling thread.
+ * Per-chain inputs and outputs are tables of n_chains pointers, each laid out as in the
+ * single-chain entry point of the sampler (initialK for collapsed; initialPi/initialTheta and pi_out
+ * for stick-breaking and full; unused tables may be NULL).  relabel is not offered here. */
+int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* X, int64_t N, int P,
+                  const int32_t* const* initialK, const double* const* initialPi,
+                  const double* const* initialTheta, int nsamples, int K /* K or maxK */, double alpha,
+                  double beta, double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed,
+                  double* const* pi_out, int32_t* const* z_out, double* const* theta_out,
+                  double* const* alpha_out);
+/* The broadcast of bmm_multi_run on a test pattern of `words` 32-bit words over the listed distinct
+ * devices, compared afterwards on every one of them.  With one device the collective still runs
+ * (library opened, communicator of one rank, ncclBroadcast): what a one-GPU box can check. */
+int bmm_multi_selfcheck(int n_devices, const int* devices, int64_t words);
+
 /* ---- resident chains --------------------------------------------------------------
  * The same samplers with the data matrix and the chain state kept in HBM between
  * calls: what the benchmark and the one-chain-per-GPU driver use.  A chain is bound
@@ -102,15 +193,28 @@ void bmm_chain_destroy(bmm_chain* c);
 #define BMM_X_INT32 1
 int bmm_chain_set_x_layout(bmm_chain* c, int layout);
 int bmm_chain_get_x_layout(const bmm_chain* c, int* layout);
-/* X from host memory or already on this device (see the layouts above for what is kept) */
+/* X from host memory or already on this device (see the layouts above for what is kept).
+ * set_data_device reads dX on the chain's own stream: it first waits for the whole device
+ * (hipDeviceSynchronize), so a matrix a kernel or a collective of the caller's is still writing
+ * is complete before it is validated and packed. */
 int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X);
 int bmm_chain_set_data_device(bmm_chain* c, const void* dX);
+/* Several chains on one device over the same data: `c` borrows the bit planes `from` holds (same
+ * device, N and P; `from` must outlive `c`).  What bmm_multi_run does for chains that share a device. */
+int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from);
+/* The chain's bit planes on its device: ceil(P/32) planes of N 32-bit words (allocated on first
+ * call).  A rank that received them from a broadcast (160 MB instead of the 4 GB int32 matrix at
+ * K=20, N=1e7, P=100) declares them complete with bmm_chain_planes_filled, which waits for the device. */
+int bmm_chain_planes(bmm_chain* c, void** dXb, int64_t* n_words);
+int bmm_chain_planes_filled(bmm_chain* c);
 /* starting state: collapsed needs 1-based labels; stick-breaking needs pi and theta;
  * dp starts from zero clusters and needs neither */
 int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1);
 int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* theta);
 /* enqueue n more sweeps on the chain's stream (returns without waiting) */
 int bmm_chain_sweeps(bmm_chain* c, int n);
+/* the same for several chains at once, one host thread per chain (chains on one device overlap) */
+int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int n);
 int bmm_chain_sync(bmm_chain* c);
 /* n more sweeps, returning the cluster sizes after each one (nk_out is n x K, row-major: sweep,
  * label) -- the per-sweep summary plot_gibbs derives from z (R/utils.R:146-173) without moving
@@ -126,8 +230,8 @@ int bmm_chain_get_params(bmm_chain* c, double* pi /*K*/, double* theta /*K x P c
  * column-major (host), row i = the normalised conditional observation i was drawn from, by label
  * (the DP's new-cluster mass under the label it would open).  This is the matrix the reference
  * stores for Stephens' relabelling (src/collapsed_gibbs.cpp:162-172, collapsed_gibbs_dp.cpp:190-200,
- * stickbreaking.cpp:129-139) -- the hand-off for relabel = TRUE, whose batch/online steps stay on the
- * host in the reference's own code.  Runs on the generic kernel; waits. */
+ * stickbreaking.cpp:129-139) -- one sweep of what the *_run_probs entry points stream (SURVEY.md section 8
+ * row f2): the weights come out of the resident resample kernel itself.  Waits. */
 int bmm_chain_sweep_probs(bmm_chain* c, double* probs_out);
 
 /* ---- one chain sharded over several ranks --------------------
@@ -137,9 +241,14 @@ int bmm_chain_sweep_probs(bmm_chain* c, double* probs_out);
  * all-reduce, done by the caller on the device pointers below); every rank then draws the same
  * pi, theta, alpha, because the Philox streams are keyed by (seed, global index) only.
  *   set_shard once before the first sweep; per sweep: shard_resample (returns with the deltas
- *   complete), all-reduce *dNk (K int32) and *dS (K*P int32) in place, shard_finish. */
+ *   complete), all-reduce *dNk (K int32) and *dS (K*P int32) in place, shard_finish.
+ *   The _async form of shard_resample returns without waiting: the caller then orders its collective
+ *   behind the chain's own HIP stream (bmm_chain_stream) and the finish behind the collective -- no
+ *   host round trip inside a sweep (multi.ShardedChain does it with a torch ExternalStream). */
 int bmm_chain_set_shard(bmm_chain* c, int64_t N_total, int64_t first_row);
 int bmm_chain_shard_resample(bmm_chain* c);
+int bmm_chain_shard_resample_async(bmm_chain* c);
+int bmm_chain_stream(bmm_chain* c, void** hip_stream);
 int bmm_chain_shard_deltas(bmm_chain* c, void** dNk, void** dS);
 int bmm_chain_shard_finish(bmm_chain* c);
 
@@ -149,13 +258,14 @@ int bmm_chain_shard_finish(bmm_chain* c);
  * about 3 us of stream time per launch, which a sampled measurement keeps out of the total) */
 int bmm_chain_profile(bmm_chain* c, int every);
 int bmm_chain_profile_read(bmm_chain* c, double* resample_ms, int64_t* resample_launches);
-/* batch size in effect (a defaulted one is rounded up to whole rounds of workgroups) */
+/* batch size in effect */
 int64_t bmm_chain_batch(const bmm_chain* c);
 /* bytes of dynamic LDS and threads per workgroup the resample kernel uses for this shape */
 int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int* grid_max);
 
-/* ---- device self-checks used by the parity tests (op: 0 log, 1 exp, 2 div by in2,
- * 3 sqrt; elementwise over n doubles, evaluated on the GPU with the spec arithmetic) */
+/* ---- device self-checks used by the parity tests (op: 0 log, 1 exp, 2 div by in2, 3 sqrt,
+ * 4 the draw's weight exponential expw; elementwise over n doubles, evaluated on the GPU with the
+ * spec arithmetic) */
 int bmm_device_math(int device, int op, const double* in, const double* in2, double* out, int64_t n);
 /* out[i] = the spec's variate number `kind` (0 gamma(shape p), 1 beta(p,q), 2 update_alpha
  * with alpha_old p, K = (int)q, N = 1000, a = b = 1) for stream index i, on the GPU */

@@ -47,11 +47,33 @@ double oracle_u01(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
 }
 
+/* Philox2x32-10: one multiply per round; the two output words make the one uniform of a draw. */
+void oracle_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t pr = (uint64_t)0xD256D193u * c0;
+        uint32_t n0 = (uint32_t)(pr >> 32) ^ key ^ c1;
+        c1 = (uint32_t)pr;
+        c0 = n0;
+        key += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+
+/* 52 random bits as the mantissa of a double in [1,2), minus 1: a uniform in [0, 1 - 2^-52] */
+double oracle_u52(uint32_t a, uint32_t b) {
+    uint64_t bits = ((uint64_t)(0x3ff00000u | (a >> 12)) << 32) | (uint32_t)((a << 20) | (b >> 12));
+    return u2d(bits) - 1.0;
+}
+
+/* the uniform of z_i in sweep j: counter (i mod 2^32, sweep), key folded from the seed (and from the
+ * high word of i) */
 double oracle_z_uniform(uint64_t seed, uint64_t i, uint32_t sweep) {
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), sweep, 0u};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
-    oracle_philox4x32_10(c, k, o);
-    return oracle_u01(o[0], o[1]);
+    uint32_t h = (uint32_t)(i >> 32);
+    uint32_t key = ((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu)) ^ ((h << 16) | (h >> 16));
+    uint32_t c[2] = {(uint32_t)i, sweep}, o[2];
+    oracle_philox2x32_10(c, key, o);
+    return oracle_u52(o[0], o[1]);
 }
 
 /* log: m in [sqrt(.5), sqrt(2)), f = m-1, s = f/(2+f), even polynomial in s. */
@@ -117,6 +139,28 @@ double oracle_exp(double x) {
     double p = __builtin_fma(t, q, t);
     if (k > 1023) { p *= 2.0; k -= 1; }
     return p * u2d((uint64_t)(k + 1023) << 52);
+}
+
+/* the draw's weight exponential, x <= 0: 256 k + j = nearest integer to x * 256/ln2 (ties to even,
+ * via the 1.5 * 2^52 sum), r = x - (256 k + j) ln2/256 in two parts, degree-4 polynomial for e^r - 1,
+ * tabulated 2^(j/256), scaled by ldexp; -inf and NaN give 0 */
+#include "exp256_table.h"
+double oracle_expw(double x) {
+    double xs = x > -1000.0 ? x : -1000.0; /* NaN -> -1000 */
+    double km = __builtin_fma(xs, 0x1.71547652b82fep+8, 0x1.8p52);
+    int32_t ki = (int32_t)(uint32_t)d2u(km);
+    double kd = km - 0x1.8p52;
+    double r = __builtin_fma(-kd, 0x1.62e42fefa39efp-9, xs);
+    r = __builtin_fma(-kd, 0x1.abc9e3b39803fp-64, r);
+    int j = ki & 255, k = ki >> 8;
+    double c = __builtin_fma(r, 4.1666666666666664354e-02, 1.6666666666666665741e-01);
+    c = __builtin_fma(r, c, 0.5);
+    double q = __builtin_fma(r * r, c, r);
+    double t = o_exp2_256[j];
+    return ldexp(__builtin_fma(t, q, t), k);
+}
+void oracle_expw_array(const double* x, double* y, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) y[i] = oracle_expw(x[i]);
 }
 
 void oracle_log_array(const double* x, double* y, int64_t n) {
@@ -191,27 +235,29 @@ double oracle_update_alpha(double alpha_old, double a, double b, double N, int K
     return pi * ga + (1.0 - pi) * gb;
 }
 
-/* Inverse-CDF draw shared by every sampler: weights w[0..n), one uniform u.
- * Picks the first k with u*tot < w[0]+..+w[k]; if rounding leaves none, the last k
- * with w[k] > 0.  Returns -1 when every weight is 0. */
+/* Inverse-CDF draw shared by every sampler: weights w[0..n), one uniform u <= 1 - 2^-52.
+ * c_k = w[0]+..+w[k] in label order, t = u * c_{n-1}; picks the number of k with t >= c_k, i.e.
+ * the first k with t < c_k.  t < c_{n-1} always holds for a finite positive total, so the pick
+ * is a category that raised the running sum.  Returns -1 when the total is not positive. */
 static int draw_index(const double* w, int n, double u) {
-    double tot = 0.0;
-    for (int k = 0; k < n; ++k) tot = tot + w[k];
-    double t = u * tot, c = 0.0;
-    int pick = -1, last = -1;
+    double c = 0.0;
+    for (int k = 0; k < n; ++k) c = c + w[k];
+    if (!(c > 0.0)) return -1;
+    double t = u * c;
+    int cnt = 0;
+    c = 0.0;
     for (int k = 0; k < n; ++k) {
-        if (w[k] > 0.0) last = k;
         c = c + w[k];
-        if (pick < 0 && t < c) pick = k;
+        if (t >= c) ++cnt;
     }
-    return pick >= 0 ? pick : last;
+    return cnt < n ? cnt : -1;
 }
-/* scores -> weights exp(score - max); returns 0 if max is -inf (degenerate) */
+/* scores -> weights expw(score - max); returns 0 if max is -inf (degenerate) */
 static int scores_to_weights(const double* score, int n, double* w) {
     double m = O_NEG_INF;
     for (int k = 0; k < n; ++k) if (score[k] > m) m = score[k];
     if (m == O_NEG_INF) return 0;
-    for (int k = 0; k < n; ++k) w[k] = oracle_exp(score[k] - m);
+    for (int k = 0; k < n; ++k) w[k] = oracle_expw(score[k] - m);
     return 1;
 }
 
@@ -254,8 +300,10 @@ static void theta_group_table(int P, int G, int K, int k, const double* theta /*
             T[g * GM + m] = t;
         }
 }
-static inline double table_sum(const double* T, const uint8_t* nib, int G) {
-    double acc = 0.0;
+/* score = ((C + T[0]) + T[1]) + ...: the category's constant term enters first (the HIP
+ * path stores C + T[0][m] as the entries of group 0) */
+static inline double table_sum(double C, const double* T, const uint8_t* nib, int G) {
+    double acc = C;
     for (int g = 0; g < G; ++g) acc = acc + T[g * GM + nib[g]];
     return acc;
 }
@@ -335,7 +383,7 @@ void oracle_collapsed_cond_spec(const int32_t* X, int64_t N, int P, const int32_
         int64_t ne = Nk[k] - minus;
         counts_group_table(beta, gamma, P, G, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
         double C = ne > 0 ? oracle_log((double)ne + alpha / (double)K) - ldN : O_NEG_INF;
-        score[k] = C + table_sum(T, nib + (size_t)i * G, G);
+        score[k] = table_sum(C, T, nib + (size_t)i * G, G);
     }
     if (scores_to_weights(score, K, w)) {
         double tot = 0.0;
@@ -397,7 +445,7 @@ void oracle_dp_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, i
         int64_t ne = Nk[k] - minus;
         counts_group_table(beta, gamma, P, G, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
         double C = ne > 0 ? oracle_log((double)ne) - ldN : O_NEG_INF;
-        logw[k] = C + table_sum(T, nib + (size_t)i * G, G);
+        logw[k] = table_sum(C, T, nib + (size_t)i * G, G);
     }
     logw[K] = dp_new_score(alpha, beta, gamma, P, ldN) + 0.0;
     if (scores_to_weights(logw, K + 1, w)) {
@@ -433,7 +481,7 @@ void oracle_sb_cond_spec(const int32_t* X, int64_t N, int P, int64_t i, int K, c
     uint8_t* nib = pack_nibbles(X, N, P, G);
     for (int k = 0; k < K; ++k) {
         theta_group_table(P, G, K, k, theta, T);
-        score[k] = oracle_log(pi[k]) + table_sum(T, nib + (size_t)i * G, G);
+        score[k] = table_sum(oracle_log(pi[k]), T, nib + (size_t)i * G, G);
     }
     if (scores_to_weights(score, K, w)) {
         double tot = 0.0;
@@ -744,7 +792,7 @@ static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, 
                 pick = draw_index(s, maxK, u);
             } else {
                 for (int k = 0; k < maxK; ++k)
-                    s[k] = C[k] + table_sum(T + (size_t)k * G * GM, nib + (size_t)i * G, G);
+                    s[k] = table_sum(C[k], T + (size_t)k * G * GM, nib + (size_t)i * G, G);
                 pick = scores_to_weights(s, maxK, w) ? draw_index(w, maxK, u) : -1;
             }
             if (pick < 0) pick = (j > 1) ? zcur[i] : 0;
@@ -905,8 +953,8 @@ static void chain_batch(ochain* c, int64_t lo, int64_t hi, uint32_t j) {
         const uint8_t* nb = c->nib + (size_t)i * G;
         const int zo = c->z[i];
         for (int k = 0; k < K; ++k) {
-            if (k == zo) c->score[k] = c->Cm[k] + table_sum(c->Tm + k * tk, nb, G);
-            else c->score[k] = c->Cp[k] + table_sum(c->Tp + k * tk, nb, G);
+            if (k == zo) c->score[k] = table_sum(c->Cm[k], c->Tm + k * tk, nb, G);
+            else c->score[k] = table_sum(c->Cp[k], c->Tp + k * tk, nb, G);
         }
         if (c->sampler == 1) c->score[K] = c->Cp[K] + 0.0;
         int pick = scores_to_weights(c->score, ncat, c->w)

@@ -11,7 +11,7 @@
  *     recomputed from the cited reference lines with NumPy (tests/golden/make_kats.py);
  *   - the bundled datasets' documented generating parameters (R/bmm-mcmc.R:13-17,
  *     31-35, 46-50) as statistical acceptance bounds;
- *   - Philox4x32-10 against the Random123 known-answer vectors.
+ *   - Philox4x32-10 and Philox2x32-10 against the Random123 known-answer vectors.
  *
  * Two restatements per sampler:
  *   *_literal : the reference algorithm as written -- per-cluster member lists,
@@ -39,7 +39,11 @@ extern "C" {
 
 /* ---- numerics (restated; must equal bmm-mcmc_amd/csrc/bmm_spec.h bit for bit) ---- */
 void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void oracle_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
 double oracle_u01(uint32_t a, uint32_t b);
+double oracle_u52(uint32_t a, uint32_t b);
+double oracle_expw(double x);
+void oracle_expw_array(const double* x, double* y, int64_t n);
 double oracle_z_uniform(uint64_t seed, uint64_t i, uint32_t sweep);
 double oracle_log(double x);
 double oracle_exp(double x);

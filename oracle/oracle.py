@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="F_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("bmm_oracle.c", "bmm_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("bmm_oracle.c", "bmm_oracle.h", "exp256_table.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -45,6 +45,10 @@ def lib():
         L.oracle_log.argtypes = [C.c_double]
         L.oracle_exp.restype = C.c_double
         L.oracle_exp.argtypes = [C.c_double]
+        L.oracle_expw.restype = C.c_double
+        L.oracle_expw.argtypes = [C.c_double]
+        L.oracle_u52.restype = C.c_double
+        L.oracle_u52.argtypes = [C.c_uint32, C.c_uint32]
         L.oracle_rgamma.restype = C.c_double
         L.oracle_rgamma.argtypes = [C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.oracle_rbeta.restype = C.c_double
@@ -80,6 +84,20 @@ def philox4x32_10(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().oracle_philox4x32_10(c, k, o)
     return tuple(int(v) for v in o)
+
+
+def philox2x32_10(ctr, key):
+    c = (C.c_uint32 * 2)(*ctr)
+    o = (C.c_uint32 * 2)()
+    lib().oracle_philox2x32_10(c, C.c_uint32(key), o)
+    return tuple(int(v) for v in o)
+
+
+def expw_array(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().oracle_expw_array(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_int64(x.size))
+    return y
 
 
 def z_uniform(seed, i, sweep):

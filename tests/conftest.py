@@ -26,3 +26,15 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+@pytest.fixture
+def dbg_lib(monkeypatch):
+    """The -DBMM_DEBUG_HOOKS variant of the library (lib/libbmmmcmc_hip_dbg.so) in place of the product for
+    one test: only it reads the kernel-steering switches BMM_DEBUG_GENERIC / BMM_DEBUG_THREADS /
+    BMM_DEBUG_NOSPLIT / BMM_X_LAYOUT_INT32, through which the parity tests reach every kernel variant."""
+    from bmm_mcmc_amd import _capi, build
+    if build.stale(build.LIB_DBG):
+        build.build(debug_variant=True)
+    monkeypatch.setattr(_capi, "_LIB", _capi.load(build.LIB_DBG))
+    return monkeypatch

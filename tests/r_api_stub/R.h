@@ -1,0 +1,2 @@
+/* TEST-ONLY, see Rinternals.h in this directory */
+#include "Rinternals.h"

@@ -35,9 +35,13 @@ def test_spec_constants_match_oracle(oracle):
 def test_default_batch_policy():
     assert bm.default_batch("stickbreaking", 1000) == 1000
     assert bm.default_batch("collapsed", 100) == 12
-    assert bm.default_batch("collapsed", 10 ** 7) == 1250000
+    # a pure function of (sampler, N): N/8 (N/16 dp), in whole multiples of 2^18 above that
+    assert bm.default_batch("collapsed", 10 ** 7) == 5 * 2 ** 18
+    assert bm.default_batch("collapsed", 10 ** 6) == 125000
+    assert bm.default_batch("dp", 10 ** 6) == 62500
     assert bm.default_batch("dp", 1600) == 100
     assert bm.default_batch("dp", 3) == 1
+    assert bm.default_batch("full", 77) == 77
 
 
 def test_argument_validation_needs_no_gpu():

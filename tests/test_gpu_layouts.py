@@ -39,12 +39,12 @@ def test_bit_planes_and_int32_run_the_same_chain(oracle, P):
 
 
 @pytest.mark.parametrize("env", [None, "1"])
-def test_run_entry_points_under_both_layouts(oracle, monkeypatch, env):
-    # the *_run entry points have no layout argument: BMM_X_LAYOUT_INT32 switches them
+def test_run_entry_points_under_both_layouts(oracle, dbg_lib, env):
+    # the *_run entry points have no layout argument: the test variant's BMM_X_LAYOUT_INT32 switches them
     if env is None:
-        monkeypatch.delenv("BMM_X_LAYOUT_INT32", raising=False)
+        dbg_lib.delenv("BMM_X_LAYOUT_INT32", raising=False)
     else:
-        monkeypatch.setenv("BMM_X_LAYOUT_INT32", env)
+        dbg_lib.setenv("BMM_X_LAYOUT_INT32", env)
     X, _, _, _ = synth(4000, 50, 4, 3)
     z0 = _z0(4000, 20, 9)
     got = bm.gibbs_collapsed(X, 6, 20, burnin=0, seed=5, batch=512, initial_K=z0)
@@ -62,6 +62,17 @@ def test_run_entry_points_under_both_layouts(oracle, monkeypatch, env):
     want = oracle.stickbreaking(X, pi0, th0, 5, 10, 0.0, 0.5, 0.5, 1, 1, 0, seed=8)
     for k in ("z", "theta", "alpha", "pi"):
         assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+def test_the_product_library_ignores_the_steering_environment(oracle, monkeypatch):
+    """The product build reads no environment: with every switch set, a *_run call still runs the
+    bit-plane resident kernel (same chain either way, so this is seen in the layout it reports)."""
+    for k in ("BMM_X_LAYOUT_INT32", "BMM_DEBUG_GENERIC", "BMM_DEBUG_NOSPLIT"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("BMM_DEBUG_THREADS", "512")
+    with bm.Chain("collapsed", 500, 8, 2, seed=1) as c:
+        assert c.x_layout() == "bits"
+        assert c.kernel_shape()["lds_bytes"] > 0   # resident kernel, not the generic path
 
 
 def test_layout_is_fixed_once_the_data_are_set():
@@ -82,11 +93,11 @@ def _capi_set(c, layout):
 # more than 32 accumulators: two lanes share an observation (SPLIT = 2), with and without the
 # own-cluster tables; the one-lane kernels (BMM_DEBUG_NOSPLIT) must give the same chain
 @pytest.mark.parametrize("nosplit", [False, True])
-def test_wide_category_counts_two_lanes_per_observation(oracle, monkeypatch, nosplit):
+def test_wide_category_counts_two_lanes_per_observation(oracle, dbg_lib, nosplit):
     if nosplit:
-        monkeypatch.setenv("BMM_DEBUG_NOSPLIT", "1")
+        dbg_lib.setenv("BMM_DEBUG_NOSPLIT", "1")
     else:
-        monkeypatch.delenv("BMM_DEBUG_NOSPLIT", raising=False)
+        dbg_lib.delenv("BMM_DEBUG_NOSPLIT", raising=False)
     for N, P, K, batch in [(3000, 40, 40, 700), (2011, 20, 64, 2011), (1500, 33, 56, 97)]:
         X, _, _, _ = synth(N, P, 4, K)
         z0 = _z0(N, K, 3)

@@ -38,6 +38,18 @@ def test_exp_bit_exact(oracle):
     assert np.array_equal(_bits(_dev(1, x)), _bits(oracle.exp_array(x)))
 
 
+def test_expw_bit_exact_including_subnormal_results(oracle):
+    """The draw's weight exponential: v_ldexp_f64 must round results below 2^-1022 exactly as the
+    host's ldexp does (the spec leaves that range to IEEE rounding instead of flushing by comparison)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-760, 0, 800000), rng.uniform(-745.5, -707.5, 300000), rng.uniform(-40, 0, 300000),
+                        -np.exp(rng.uniform(-40, 3, 100000)),
+                        [0.0, -0.0, -708.0, -745.13, -745.14, -746.0, -1000.0, -1e300, -np.inf, np.nan]])
+    got, want = _dev(4, x), oracle.expw_array(x)
+    assert np.array_equal(_bits(got), _bits(want))
+    assert got[-1] == 0.0 and got[-2] == 0.0 and got[0 - 10] == 1.0
+
+
 def test_division_and_sqrt_are_correctly_rounded():
     rng = np.random.default_rng(3)
     a = np.exp(rng.uniform(-300, 300, 1000000)) * rng.choice([-1.0, 1.0], 1000000)

@@ -1,0 +1,138 @@
+"""Several chains in one call and on one device (include/bmm_mcmc.h: bmm_multi_run, bmm_chain_share_data,
+bmm_chains_sweeps) -- through the C ABI on one GPU: chains on devices {0, 0, ...} need no collective, share
+one copy of the bit planes and run on their own streams from their own host threads; each must still be its
+oracle chain (seed + c) bit for bit.  The RCCL broadcast itself is exercised on the one device the box has by
+bmm_multi_selfcheck (library opened, communicator built, ncclBroadcast run, words compared)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bmm_mcmc_amd as bm
+from bmm_mcmc_amd import _capi
+from util import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _z0(N, K, seed):
+    return np.random.default_rng(seed).integers(1, K + 1, N).astype(np.int32)
+
+
+def test_two_collapsed_chains_on_one_device_equal_their_oracle_chains(oracle):
+    X, _, _, _ = synth(6000, 40, 5, 12)
+    N, K, seed = 6000, 8, 500
+    z0s = [_z0(N, K, 1), _z0(N, K, 2)]
+    got = bm.gibbs_collapsed(X, 9, K, burnin=2, seed=seed, batch=1000, chains=2, devices=[0, 0], initial_K=z0s)
+    assert isinstance(got, list) and len(got) == 2
+    for c in range(2):
+        want = oracle.collapsed(X, z0s[c], 9, K, 0.0, 0.5, 0.5, 1, 1, 2, seed=seed + c, batch=1000)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[c][k], want[k], equal_nan=True), (c, k)
+        assert got[c]["permutations"].shape == (7, K)
+    assert not np.array_equal(got[0]["z"], got[1]["z"])   # different keys, different chains
+
+
+def test_four_chains_of_the_other_samplers(oracle):
+    X, _, _, _ = synth(4000, 30, 4, 7)
+    got = bm.gibbs_dp(X, 7, burnin=1, maxK=12, seed=40, batch=250, chains=4)          # devices=None: all on 0
+    for c in range(4):
+        want = oracle.dp(X, 7, 0.0, 0.5, 0.5, 1, 1, 1, 12, seed=40 + c, batch=250)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[c][k], want[k], equal_nan=True), (c, k)
+    rng = np.random.default_rng(3)
+    pis = [rng.dirichlet(np.ones(9)) for _ in range(3)]
+    ths = [rng.random((9, 30)) for _ in range(3)]
+    got = bm.gibbs_stickbreaking(X, 6, 9, burnin=0, seed=11, chains=3, devices=[0, 0, 0], initial_pi=pis,
+                                 initial_theta=ths)
+    for c in range(3):
+        want = oracle.stickbreaking(X, pis[c], ths[c], 6, 9, 0.0, 0.5, 0.5, 1, 1, 0, seed=11 + c)
+        for k in ("pi", "z", "theta", "alpha"):
+            assert np.array_equal(got[c][k], want[k], equal_nan=True), (c, k)
+
+
+def test_multi_run_argument_errors():
+    X, _, _, _ = synth(300, 6, 2, 1)
+    with pytest.raises(ValueError, match="one device per chain"):
+        bm.gibbs_dp(X, 5, seed=1, chains=2, devices=[0])
+    with pytest.raises(bm.BmmError, match="out of range"):
+        bm.gibbs_dp(X, 5, seed=1, chains=2, devices=[0, 99])
+
+
+def test_rccl_broadcast_selfcheck_on_this_device():
+    dev = (C.c_int * 1)(0)
+    _capi.check(_capi.lib().bmm_multi_selfcheck(C.c_int(1), dev, C.c_int64(1 << 20)))
+
+
+def test_resident_chains_sharing_planes_and_swept_together(oracle):
+    """chains_per_gpu: four resident chains over ONE copy of the bit planes, advanced by one host thread each."""
+    N, P, K = 20000, 50, 20
+    X, _, _, _ = synth(N, P, 6, 5)
+    chains = [bm.Chain("collapsed", N, P, K, batch=2500, seed=900 + c) for c in range(4)]
+    try:
+        chains[0].set_data(X)
+        for c in chains[1:]:
+            c.share_data(chains[0])
+        z0s = [_z0(N, K, 30 + c) for c in range(4)]
+        for c, z0 in zip(chains, z0s):
+            c.set_initial_labels(z0)
+        bm.sweep_chains(chains, 3)
+        bm.sweep_chains(chains, 2)
+        for c in chains:
+            c.sync()
+        for i, c in enumerate(chains):
+            want = oracle.collapsed(X, z0s[i], 6, K, 0.0, 0.5, 0.5, 1, 1, 5, seed=900 + i, batch=2500)
+            assert np.array_equal(c.labels(), want["z"][0]), i
+            assert c.alpha() == want["alpha"][0, 0]
+        with pytest.raises(bm.BmmError, match="already has its data"):
+            chains[1].share_data(chains[0])
+    finally:
+        for c in chains[1:] + chains[:1]:   # borrowers first
+            c.close()
+
+
+def test_planes_handed_over_by_the_caller_equal_a_packed_matrix(oracle):
+    """What a rank of the multi-process launcher does after the broadcast: it never sees the int32 matrix."""
+    import torch
+    from bmm_mcmc_amd import multi
+    N, P, K = 5000, 70, 6
+    X, _, _, _ = synth(N, P, 4, 3)
+    z0 = _z0(N, K, 8)
+    with bm.Chain("collapsed", N, P, K, batch=700, seed=5) as src, bm.Chain("collapsed", N, P, K, batch=700, seed=5) as dst:
+        src.set_data(X)
+        a, n = src.planes()
+        b, n2 = dst.planes()
+        assert n == n2 == 3 * N
+        multi.device_ints(b, n, torch.device("cuda", 0)).copy_(multi.device_ints(a, n, torch.device("cuda", 0)))
+        dst.planes_filled()            # waits for the device: the copy above ran on torch's stream
+        for c in (src, dst):
+            c.set_initial_labels(z0)
+            c.sweeps(4)
+        assert np.array_equal(src.labels(), dst.labels())
+        want = oracle.collapsed(X, z0, 5, K, 0.0, 0.5, 0.5, 1, 1, 4, seed=5, batch=700)
+        assert np.array_equal(dst.labels(), want["z"][0])
+
+
+def test_set_data_device_waits_for_the_producer(oracle):
+    """bmm_chain_set_data_device right behind kernels still writing X on another stream: the
+    chain must pack the finished matrix, not what was there before."""
+    import torch
+    N, P, K = 400000, 24, 4
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    Xt = torch.zeros((P, N), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(20):                                   # a queue of work ahead of the final values
+            Xt.copy_((torch.rand((P, N), generator=g, device=dev) < 0.3).to(torch.int32))
+        with bm.Chain("collapsed", N, P, K, seed=1) as ch:
+            ch.set_data_device(Xt.data_ptr(), keepalive=Xt)   # no synchronize in between
+            z0 = _z0(N, K, 2)
+            ch.set_initial_labels(z0)
+            ch.sweeps(0)
+            nk, s = ch.counts()
+    Xh = Xt.cpu().numpy().T
+    assert np.array_equal(nk, np.bincount(z0 - 1, minlength=K))
+    assert np.array_equal(s, np.stack([Xh[z0 == k + 1].sum(axis=0) for k in range(K)]))

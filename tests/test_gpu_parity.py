@@ -33,12 +33,14 @@ def test_collapsed_bundled_c1_small(oracle, batch):
     _same(got, want, ["z", "theta", "alpha"])
 
 
-def test_collapsed_config_c1_full(oracle):
-    # BASELINE config 1: bundled K2_N100_P5, 1 chain, 1000 iterations, burn-in 100
+@pytest.mark.parametrize("batch", [1, 25])
+def test_collapsed_config_c1_full(oracle, batch):
+    # BASELINE config 1: bundled K2_N100_P5, 1 chain, 1000 iterations, burn-in 100 -- at batch = 1, the
+    # reference's sequential scan (100 launches per sweep: the chain the reference itself runs), and batched
     X = load_dataset("K2_N100_P5")
     z0 = _z0(100, 2, 17)
-    got = bm.gibbs_collapsed(X, 1000, 2, seed=2019, batch=25, initial_K=z0)
-    want = oracle.collapsed(X, z0, 1000, 2, 0.0, 0.5, 0.5, 1, 1, 100, seed=2019, batch=25)
+    got = bm.gibbs_collapsed(X, 1000, 2, seed=2019, batch=batch, initial_K=z0)
+    want = oracle.collapsed(X, z0, 1000, 2, 0.0, 0.5, 0.5, 1, 1, 100, seed=2019, batch=batch)
     _same(got, want, ["z", "theta", "alpha"])
     np.testing.assert_allclose(proportions(got["z"], 2), [0.7, 0.3], atol=0.05)
 
@@ -316,6 +318,33 @@ def test_sweep_probabilities_are_the_conditionals_the_draw_used(oracle):
     for i in (0, 17, N - 1):
         _, norm = oracle.sb_cond(X, i, pi0, th0, spec=True)
         assert np.array_equal(probs[i], norm)
+    # DP: the new-cluster mass is filed under the label it would open; batched (3 launches per sweep)
+    with bm.Chain("dp", N, 5, 6, alpha=1.0, batch=100, seed=9) as ch:
+        ch.set_data(X)
+        ch.sweeps(3)
+        zb = ch.labels()
+        probs = ch.sweep_probs()
+    assert probs.shape == (N, 6)
+    np.testing.assert_allclose(probs.sum(axis=1), 1.0, rtol=0, atol=1e-14)
+    used = np.bincount(zb - 1, minlength=6) > 0
+    free = int(np.argmin(used)) if not used.all() else -1
+    _, norm = oracle.dp_cond(X, zb, 0, 6, 1.0, 0.5, 0.5, spec=True)   # observation 0: first batch, state zb
+    want0 = norm[:6].copy()
+    if free >= 0:
+        want0[free] = norm[6]
+    assert np.array_equal(probs[0], want0)
+    # the int32 layout has no emitting twin: its hand-off sweeps run on the generic kernel, same numbers
+    with bm.Chain("collapsed", N, 5, K, alpha=1.5, batch=N, seed=4, x_layout="int32") as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        p32 = ch.sweep_probs()
+    with bm.Chain("collapsed", N, 5, K, alpha=1.5, batch=N, seed=4) as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        pbits = ch.sweep_probs()
+    assert np.array_equal(p32, pbits)
 
 
 # ---------------------------------------------------------------- generic path (any shape)
@@ -344,13 +373,16 @@ def test_dp_and_explicit_samplers_beyond_the_resident_kernel(oracle):
     _same(got, want, ["z", "theta", "alpha", "pi"])
 
 
-def test_generic_path_equals_resident_path_on_an_ordinary_shape(oracle, monkeypatch):
+def test_generic_path_equals_resident_path_on_an_ordinary_shape(oracle, dbg_lib):
     X, _, _, _ = synth(3000, 33, 4, 35)
     z0 = _z0(3000, 7, 6)
+    dbg_lib.delenv("BMM_DEBUG_GENERIC", raising=False)
     fast = bm.gibbs_collapsed(X, 6, 7, burnin=0, seed=21, batch=512, initial_K=z0)
-    monkeypatch.setenv("BMM_DEBUG_GENERIC", "1")
+    dbg_lib.setenv("BMM_DEBUG_GENERIC", "1")   # read by the test variant of the library only
     slow = bm.gibbs_collapsed(X, 6, 7, burnin=0, seed=21, batch=512, initial_K=z0)
     _same(fast, slow, ["z", "theta", "alpha"])
+    want = oracle.collapsed(X, z0, 6, 7, 0.0, 0.5, 0.5, 1, 1, 0, seed=21, batch=512)
+    _same(fast, want, ["z", "theta", "alpha"])
 
 
 def test_unsupported_shapes_fail_loudly():

@@ -11,10 +11,26 @@ def test_philox_random123_kats(oracle):
                                 (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
 
 
+def test_philox2x32_random123_kats(oracle):
+    # Random123 kat_vectors, philox2x32 10 rounds: the generator of the per-observation uniform
+    assert oracle.philox2x32_10((0, 0), 0) == (0xff1dae59, 0x6cd10df2)
+    f = 0xffffffff
+    assert oracle.philox2x32_10((f, f), f) == (0x2c3f628b, 0xab4fd7ad)
+    assert oracle.philox2x32_10((0x243f6a88, 0x85a308d3), 0x13198a2e) == (0xdd7ce038, 0xf62a4c12)
+
+
 def test_uniform_range_and_resolution(oracle):
     L = oracle.lib()
     assert L.oracle_u01(0, 0) == 0.0
     assert L.oracle_u01(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -53
+    # the draw's uniform: 52 bits, largest value 1 - 2^-52, so that u * t < t for every finite t > 0
+    assert L.oracle_u52(0, 0) == 0.0
+    assert L.oracle_u52(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -52
+    assert L.oracle_u52(0x80000000, 0) == 0.5
+    assert L.oracle_u52(0, 0x1000) == 2.0 ** -52 and L.oracle_u52(0, 0xfff) == 0.0
+    umax = 1.0 - 2.0 ** -52
+    t = np.concatenate([np.random.default_rng(0).uniform(1.0, 64.0, 100000), [1.0, 2.0, 1.0 + 2.0 ** -52, 20.0]])
+    assert (umax * t < t).all()
     u = np.array([oracle.z_uniform(7, i, 3) for i in range(20000)])
     assert 0.0 <= u.min() and u.max() < 1.0
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
@@ -52,6 +68,22 @@ def test_exp_within_one_ulp_of_libm_and_flush(oracle):
     assert L.oracle_exp(-708.5) == 0.0 and L.oracle_exp(-np.inf) == 0.0
     assert L.oracle_exp(710.0) == np.inf
     assert np.isnan(L.oracle_exp(np.nan))
+
+
+def test_expw_within_one_ulp_and_underflow(oracle):
+    """The draw's weight exponential (x <= 0): < 1 ulp of libm in the normal range, correctly
+    rounded subnormals by construction (ldexp), exact zeros below and for -inf / NaN."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-708, 0, 400000), rng.uniform(-40, 0, 200000), -np.exp(rng.uniform(-40, 3, 100000))])
+    y = oracle.expw_array(x)
+    assert _ulps(y, np.exp(x)).max() <= 1.0
+    L = oracle.lib()
+    assert L.oracle_expw(0.0) == 1.0
+    assert L.oracle_expw(-np.inf) == 0.0 and L.oracle_expw(np.nan) == 0.0 and L.oracle_expw(-1e6) == 0.0
+    assert L.oracle_expw(-746.0) == 0.0
+    xs = rng.uniform(-745, -708.4, 20000)   # subnormal results: within one spacing of libm's
+    ys = oracle.expw_array(xs)
+    assert (np.abs(ys - np.exp(xs)) <= 2 * 4.94e-324 + 1e-15 * np.exp(xs)).all() and (ys > 0).all()
 
 
 def test_gamma_beta_moments(oracle):
