@@ -47,9 +47,33 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 
 
+def cgroup_cpus():
+    """CPU quota of this process's cgroup in whole CPUs (cgroup v2 cpu.max / v1 cfs quota), or None"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except Exception:
+        pass
+    return None
+
+
 def socket_cores():
-    """(cores of one socket, threads this process may run on)"""
+    """(cores of one socket, CPUs this process may actually use: affinity mask capped by the cgroup's CPU
+    quota and by BMM_BENCH_CPUS -- a one-GPU box of this pool grants 16 of the host's CPUs)"""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpus()
+    if quota:
+        avail = min(avail, quota)
+    if os.environ.get("BMM_BENCH_CPUS"):
+        avail = min(avail, int(os.environ["BMM_BENCH_CPUS"]))
     cores = None
     try:
         out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
@@ -263,10 +287,18 @@ def main():
         """the oracle's sufficient-statistics chain on this box's cores; literal form extrapolated"""
         from oracle import oracle
         per_socket, avail = socket_cores()
-        threads = max(1, min(per_socket, avail))
         rows = min(args.cpu_rows, N)
         Xh = np.asfortranarray(Xdev[:, :rows].t().cpu().numpy())  # first `rows` (shuffled) rows
         cb = max(1, min(batch, rows))
+        # one socket's cores where the box grants them; a one-GPU box of this pool shares its host, and its
+        # CPU share (16) can be below what the affinity mask shows -- so the thread count is the better of
+        # {16, one socket} by a one-sweep probe on a fifth of the sample, both probes reported
+        cand = sorted({max(1, min(16, avail)), max(1, min(per_socket, avail))})
+        probes = {}
+        Xp = np.asfortranarray(Xh[:max(1000, rows // 5)])
+        for t in cand:
+            probes[t] = t * Xp.shape[0] / oracle.time_sweeps(sampler, Xp, K, 1, max(1, min(cb, Xp.shape[0])), 1000, t)
+        threads = max(probes, key=probes.get)
         probe = oracle.time_sweeps(sampler, Xh, K, 1, cb, 1000, threads)  # size the leg to ~cpu-seconds
         cpu_sweeps = int(max(2, min(200, round(args.cpu_seconds / max(probe, 1e-3)))))
         secs = oracle.time_sweeps(sampler, Xh, K, cpu_sweeps, cb, 1000, threads)
@@ -275,7 +307,8 @@ def main():
                "sample": "%s: %d independent chains (one per thread) x %d sweeps over the first %d rows; "
                          "allocations/s / N" % (label, threads, cpu_sweeps, rows),
                "allocations_per_s": alloc_s, "seconds": secs,
-               "cores_per_socket": per_socket, "cpus_available_to_this_process": avail}
+               "cores_per_socket": per_socket, "cpus_available_to_this_process": avail,
+               "thread_count_probe_allocations_per_s": {str(t): v for t, v in probes.items()}}
         if threads < per_socket:
             out["one_socket_extrapolated"] = {
                 "value": alloc_s / N * per_socket / threads,

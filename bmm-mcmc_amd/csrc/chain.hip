@@ -607,7 +607,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
-    const size_t hist_bytes = ((size_t)K * P + K) * sizeof(int32_t);
+    const size_t hist_bytes = ((size_t)K * P + K + 4) * sizeof(int32_t);  // histogram + the chunk counter
     c->bits = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
     c->generic = p.KT < 0 || P > kMaxP || dbg_env("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {

@@ -467,11 +467,42 @@ __device__ __forceinline__ unsigned nibble_of(int g, uint32_t b0, uint32_t b1, u
     return (word >> ((g & 7) * 4)) & 15u;
 }
 
-// Sufficient-statistic deltas of one wave's movers into the workgroup's LDS histogram:
-// one mover at a time, one feature per lane (conflict-free, integer, order-independent).
+// Sufficient-statistic deltas of one wave's movers into the workgroup's LDS histogram (integer LDS
+// atomics: order-independent, deterministic).  Cluster sizes: every mover lane adds its own +1 / -1.
+// Feature counts, two forms chosen per wave by the number of movers:
+//   few movers    one mover at a time by the whole wave: its bits broadcast by readlane, one feature
+//                 per lane (conflict-free), about 40 instructions per mover;
+//   many movers   every mover lane walks the set bits of its own words (LDS atomics resolve lanes that
+//                 meet on a cell): about 10 instructions per set bit of the densest mover, whatever the
+//                 number of movers -- the first sweeps from a random allocation, where all 64 lanes
+//                 move, and samplers whose posteriors keep many observations undecided.
 __device__ __forceinline__ void count_movers(bool moves, int zfrom, int zto, uint32_t b0, uint32_t b1,
                                              uint32_t b2, uint32_t b3, int32_t* hist, int K, int P, int lane) {
     unsigned long long movers = __ballot(moves);
+    if (!movers) return;
+    if (moves) {
+        atomicAdd(&hist[K * P + zto], 1);
+        if (zfrom >= 0) atomicAdd(&hist[K * P + zfrom], -1);
+    }
+    const int thr = P >= 16 ? P >> 3 : 2;
+    if (__popcll(movers) > thr) {  // uniform
+        if (moves) {
+            int32_t* const hn = hist + zto * P;
+            int32_t* const ho = hist + (zfrom < 0 ? 0 : zfrom) * P;
+            const int W = (P + 31) >> 5;
+#pragma unroll 1
+            for (int w = 0; w < W; ++w) {
+                uint32_t bits = w == 0 ? b0 : (w == 1 ? b1 : (w == 2 ? b2 : b3));
+                while (bits) {
+                    const int d = (w << 5) + __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    atomicAdd(&hn[d], 1);
+                    if (zfrom >= 0) atomicAdd(&ho[d], -1);
+                }
+            }
+        }
+        return;
+    }
     while (movers) {
         const int src = __ffsll((long long)movers) - 1;
         movers &= movers - 1;
@@ -488,10 +519,6 @@ __device__ __forceinline__ void count_movers(bool moves, int zfrom, int zto, uin
         if (lane + 64 < P && ((hi_w >> sh) & 1u)) {
             atomicAdd(&hist[mzn * P + lane + 64], 1);
             if (mzo >= 0) atomicAdd(&hist[mzo * P + lane + 64], -1);
-        }
-        if (lane == 0) {
-            atomicAdd(&hist[K * P + mzn], 1);
-            if (mzo >= 0) atomicAdd(&hist[K * P + mzo], -1);
         }
     }
 }
@@ -644,11 +671,22 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int half = SPLIT == 2 ? lane >> 5 : 0;  // which half of the categories this lane scores
     const int kb = half * KH;
-    const int64_t ntiles = (a.hi - a.lo + OT - 1) / OT;
+    // Work is handed out per wave, in chunks of OW consecutive observations: workgroup b owns the chunks
+    // [b * cpw, (b + 1) * cpw) of the batch; a wave's first chunk is fixed (its loads go out before the
+    // tables are staged), every further one comes from a counter in LDS -- the waves of a workgroup then
+    // finish within one chunk of each other whatever order the SIMDs served them in.  The statistics are
+    // integer sums and every label is stored by observation index, so results do not depend on who took what.
+    constexpr int OW = 64 / SPLIT;
+    constexpr int NW = NT / 64;  // waves per workgroup
+    const int64_t nchunks = (a.hi - a.lo + OW - 1) / OW;
+    const int64_t cpw = (nchunks + gridDim.x - 1) / gridDim.x;
+    const int64_t wg_c0 = (int64_t)blockIdx.x * cpw;
+    const int64_t wg_cn = nchunks - wg_c0 < cpw ? nchunks - wg_c0 : cpw;  // chunks of this workgroup (may be <= 0)
+    (void)OT;
     auto tpos = [&](int64_t t) -> TilePos {
-        if (SPLIT == 1) return tile_pos(a, t, NT, tid, lane);
+        if (SPLIT == 1) return tile_pos(a, t, 64, lane, lane);
         TilePos q;  // lanes l and l + 32 of a wave stand on the same observation
-        q.i = a.lo + t * OT + (tid >> 6) * 32 + (lane & 31);
+        q.i = a.lo + t * OW + (lane & 31);
         q.valid = q.i < a.hi;
         q.ic = q.valid ? q.i : a.hi - 1;
         q.voff = 0; q.base = nullptr;
@@ -660,8 +698,10 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     const int nstages = BITS ? W : (P + STG - 1) / STG;
     constexpr int GPSX = BITS ? 8 : GPS;
 
-    int64_t tile = blockIdx.x;
-    const bool has_tile = tile < ntiles;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int64_t tile = wg_c0 + wave;  // chunk index within the batch
+    const bool has_tile = wave < wg_cn;
+    int* const next_chunk = hist + K * P + K;  // LDS counter behind the histogram
     uint32_t st[STG];
 #pragma unroll
     for (int u = 0; u < STG; ++u) st[u] = 0;
@@ -693,6 +733,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         }
     }
     for (int i = tid; i < K * P + K; i += NT) hist[i] = 0;
+    if (tid == 0) *next_chunk = NW;  // chunks 0 .. NW-1 of the workgroup are the waves' first ones
     __syncthreads();
 
     // DP bookkeeping shared by the whole batch (collapsed_gibbs_dp.cpp:166-171,212-231)
@@ -736,8 +777,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             // the in-order VMEM stream: a store still pending at the loop latch would make the
             // compiler wait vmcnt(0) there, i.e. a full write round trip per tile
             if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
-            const int64_t next = tile + gridDim.x;
-            const bool has_next = next < ntiles;  // uniform
+            int nc = 0;
+            if (lane == 0) nc = atomicAdd(next_chunk, 1);
+            nc = __builtin_amdgcn_readfirstlane(nc);
+            const int64_t next = wg_c0 + nc;
+            const bool has_next = nc < wg_cn;  // uniform
             const TilePos npos = tpos(has_next ? next : tile);
             uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             int zo_next = -1;
@@ -759,7 +803,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 const uint32_t cur = h == 0 ? b0 : (h == 1 ? b1 : (h == 2 ? b2 : b3));  // BITS: this stage's word
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
+#ifdef BMM_EXP_NOLOOKUP  // timing experiment only (tools/exp_lib.sh): one lookup group per stage
+                const int g_hi = h * GPSX + 1 < G ? h * GPSX + 1 : G;
+#else
                 const int g_hi = G < (h + 1) * GPSX ? G : (h + 1) * GPSX;
+#endif
 #pragma unroll 1
                 for (int g = h * GPSX; g < g_hi; ++g) {
                     const unsigned nib = BITS ? (cur >> ((g & 7) * 4)) & 15u : nibble_of(g, b0, b1, b2, b3);
@@ -802,7 +850,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double run = 0.0;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
+#ifdef BMM_EXP_NODRAW  // timing experiment only: no exponentials
+                const double w = (acc[k] - m) + 2.0;
+#else
                 const double w = expw_tab(acc[k] - m, ET);
+#endif
                 if (EMIT && kb + k < p.Kc && pos.valid) a.wts[(int64_t)(kb + k) * p.N + pos.i] = w;
                 if (SPLIT == 1) { run = run + w; acc[k] = run; }
                 else acc[k] = w;

@@ -8,8 +8,9 @@ tail -3 gpurun_out/gpu_tests.log
 show() { python3 - "$1" "$2" <<'PY'
 import json, sys
 r = json.load(open(sys.argv[2])); f = r["roofline"]
-print("%-8s %8.3f ms/sweep  kern %7.3f ms  %6.0f GB/s  frac %.3f  thr %d lds %d" % (
-    sys.argv[1], r["ms_per_step"], f["kernel_ms_per_sweep"], f["achieved"], f["frac"], f["threads"], f["lds_bytes"]))
+print("%-8s %8.3f ms/sweep  kern %7.3f ms  bound %s frac %s  hbm %.0f GB/s  thr %d lds %d" % (
+    sys.argv[1], r["ms_per_step"], f["kernel_ms_per_sweep"], f["bound"], f.get("frac"), f.get("hbm_GBps", f.get("achieved") or 0),
+    f["threads"], f["lds_bytes"]))
 PY
 }
 for w in c5 ns c3 c4 c2; do

@@ -1,5 +1,9 @@
 #!/bin/bash
-# workgroup-size experiment (BMM_DEBUG_THREADS) on a workload: tools/try_threads.sh c5 1024 768 512
+# workgroup-size experiment on a workload: tools/try_threads.sh c5 1024 768 512
+# (BMM_DEBUG_THREADS is read by the -DBMM_DEBUG_HOOKS test variant of the library only, loaded here
+# through BMM_LIB_PATH)
+cd "$(dirname "$0")/.."
+export BMM_LIB_PATH=$(pwd)/bmm-mcmc_amd/lib/libbmmmcmc_hip_dbg.so
 w=$1; shift
 for nt in default "$@"; do
   if [ $nt = default ]; then unset BMM_DEBUG_THREADS; else export BMM_DEBUG_THREADS=$nt; fi
