@@ -32,7 +32,7 @@
 namespace bmm {
 
 // ---------------------------------------------------------------- constants
-constexpr int kGroupW = 4;             // features per lookup group (nibble tables)
+constexpr int kGroupW = 4;             // features per lookup group (16-entry tables; see DESIGN.md for why not 5)
 constexpr int kGroupM = 1 << kGroupW;  // entries per group table
 
 // Philox stream ids (counter word 3)

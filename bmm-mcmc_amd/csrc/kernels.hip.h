@@ -29,6 +29,8 @@ namespace bmm {
 typedef __attribute__((address_space(3))) double lds_f64;  // LDS-qualified, keeps ds_read under volatile
 
 constexpr int kMaxP = 128;      // fast path: 4 bit-words per observation
+constexpr int kMaxG = (kMaxP + kGroupW - 1) / kGroupW;  // lookup groups on the fast path
+constexpr int kChunkP = kMaxP / kGroupW * kGroupW;      // features per table-building chunk: whole groups
 constexpr int kMaxCats = 64;    // fast path: clusters (+ the DP's new-cluster option)
 constexpr int kMaxCatsAny = 1024;  // generic path
 
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
         cst[0] = cp; cst[1] = cm;  // read after the first barrier below
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
     }
-    for (int c0 = 0; c0 < P; c0 += kMaxP) {  // kMaxP features (32 groups) at a time
-        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
+    for (int c0 = 0; c0 < P; c0 += kChunkP) {  // kChunkP features (whole groups) at a time
+        const int pc = P - c0 < kChunkP ? P - c0 : kChunkP;
         int32_t s = 0;
         if (dl < pc) {
             const int d = c0 + dl;
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
         tab[L.cm() + k] = neg_inf();
         reinterpret_cast<int32_t*>(tab + L.nk())[k] = is_label ? Nk[k] : 0;
     }
-    for (int c0 = 0; c0 < P; c0 += kMaxP) {
-        const int pc = P - c0 < kMaxP ? P - c0 : kMaxP;
+    for (int c0 = 0; c0 < P; c0 += kChunkP) {
+        const int pc = P - c0 < kChunkP ? P - c0 : kChunkP;
         const int d = c0 + dl;
         if (draw && is_label && dl < pc) {
             const int32_t ck = Nk[k], V = S[(size_t)k * P + d];
@@ -462,9 +464,15 @@ __device__ __forceinline__ void put_stage(uint32_t v, int h, uint32_t& b0, uint3
     b2 |= w == 2 ? sh : 0u;
     b3 |= w == 3 ? sh : 0u;
 }
-__device__ __forceinline__ unsigned nibble_of(int g, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
-    const uint32_t word = g < 8 ? b0 : (g < 16 ? b1 : (g < 24 ? b2 : b3));
-    return (word >> ((g & 7) * 4)) & 15u;
+// The kGroupW-bit field of lookup group g (bits [g*kGroupW, (g+1)*kGroupW) of the observation's 128-bit
+// pattern); a field may straddle two words.  g uniform.
+__device__ __forceinline__ uint32_t word_of(int w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    return w == 0 ? b0 : (w == 1 ? b1 : (w == 2 ? b2 : (w == 3 ? b3 : 0u)));
+}
+__device__ __forceinline__ unsigned group_field(int g, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    const int o = g * kGroupW, w = o >> 5;
+    return __builtin_amdgcn_alignbit(word_of(w + 1, b0, b1, b2, b3), word_of(w, b0, b1, b2, b3), o & 31) &
+           (unsigned)(kGroupM - 1);
 }
 
 // Sufficient-statistic deltas of one wave's movers into the workgroup's LDS histogram (integer LDS
@@ -649,7 +657,7 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
     static_assert(SPLIT == 1 || (SPLIT == 2 && BITS && MINUS != 2 && KT % 2 == 0), "split form");
-    constexpr int GPS = STG / kGroupW;  // lookup groups per stage
+    constexpr int SB = BITS ? 32 : STG;  // start bits of the lookup groups one stage scores
     constexpr int KH = KT / SPLIT;      // accumulators per lane
     constexpr int OT = NT / SPLIT;      // observations per tile
     constexpr int CH = SPLIT == 2 ? (KH <= 20 ? KH : KH / 2)
@@ -696,7 +704,6 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     // (up to four) words of the next tile being loaded with the first stage
     const int W = (P + 31) / 32;
     const int nstages = BITS ? W : (P + STG - 1) / STG;
-    constexpr int GPSX = BITS ? 8 : GPS;
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int64_t tile = wg_c0 + wave;  // chunk index within the batch
@@ -773,9 +780,31 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         int zn_prev = 0;
         int64_t i_prev = -1;  // < 0: nothing to store yet
         for (;;) {
+            const int zoc = zo < 0 ? 0 : zo;
+            double acc_own = 0.0;
+            if (MINUS == 2) {
+                // own-cluster ("minus self") tables too big for LDS beside Tp: gathered from global memory
+                // (L2-resident, one entry per group: 1/K of the lookups), all of a tile's gathers in flight
+                // together, in two halves, before the accumulators are live; summed in group order
+#pragma unroll
+                for (int g0 = 0; g0 < kMaxG; g0 += (kMaxG + 1) / 2) {
+                    double ow[(kMaxG + 1) / 2];
+#pragma unroll
+                    for (int u = 0; u < (kMaxG + 1) / 2; ++u) {
+                        const int g = g0 + u;
+                        ow[u] = 0.0;
+                        if (g < kMaxG && g < G)
+                            ow[u] = TmG[((size_t)g * KT + zoc) * kGroupM + group_field(g, b0, b1, b2, b3)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < (kMaxG + 1) / 2; ++u)
+                        if (g0 + u < kMaxG && g0 + u < G) acc_own = acc_own + ow[u];
+                }
+            }
             // the previous tile's labels go out here, ahead of this iteration's stage loads in
-            // the in-order VMEM stream: a store still pending at the loop latch would make the
-            // compiler wait vmcnt(0) there, i.e. a full write round trip per tile
+            // the in-order VMEM stream (and behind the gathers above, whose wait would otherwise cover
+            // a write round trip): a store still pending at the loop latch would make the compiler
+            // wait vmcnt(0) there
             if (i_prev >= 0) a.z_out[i_prev] = zn_prev;
             int nc = 0;
             if (lane == 0) nc = atomicAdd(next_chunk, 1);
@@ -785,7 +814,6 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             const TilePos npos = tpos(has_next ? next : tile);
             uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             int zo_next = -1;
-            const int zoc = zo < 0 ? 0 : zo;
 
             // ---- scoring: K * G conflict-free LDS lookups.  One outer iteration = one feature
             // stage: its loads for the NEXT tile are issued first, fly during the four lookup
@@ -793,28 +821,31 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double acc[KH];
 #pragma unroll
             for (int k = 0; k < KH; ++k) acc[k] = 0.0;
-            double acc_own = 0.0;
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
                 if (has_next) {
                     if (BITS) { if (h == 0) load_words(a.Xb, p.N, W, npos.ic, n0, n1, n2, n3); }
                     else issue_stage<STG>(npos, p.N, P, h, st);
                 }
-                const uint32_t cur = h == 0 ? b0 : (h == 1 ? b1 : (h == 2 ? b2 : b3));  // BITS: this stage's word
+                // the lookup groups whose first bit lies in this stage's span [SB*h, SB*(h+1)): one word
+                // `cur` holds it, a field may run on into `nxt`
+                const int wd = (SB * h) >> 5;
+                const uint32_t cur = word_of(wd, b0, b1, b2, b3), nxt = word_of(wd + 1, b0, b1, b2, b3);
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
+                const int g_lo = (SB * h + kGroupW - 1) / kGroupW;
+                int g_hi = (SB * (h + 1) + kGroupW - 1) / kGroupW;
+                g_hi = g_hi < G ? g_hi : G;
 #ifdef BMM_EXP_NOLOOKUP  // timing experiment only (tools/exp_lib.sh): one lookup group per stage
-                const int g_hi = h * GPSX + 1 < G ? h * GPSX + 1 : G;
-#else
-                const int g_hi = G < (h + 1) * GPSX ? G : (h + 1) * GPSX;
+                g_hi = g_lo + 1 < g_hi ? g_lo + 1 : g_hi;
 #endif
 #pragma unroll 1
-                for (int g = h * GPSX; g < g_hi; ++g) {
-                    const unsigned nib = BITS ? (cur >> ((g & 7) * 4)) & 15u : nibble_of(g, b0, b1, b2, b3);
+                for (int g = g_lo; g < g_hi; ++g) {
+                    const unsigned nib = __builtin_amdgcn_alignbit(nxt, cur, (unsigned)(g * kGroupW - 32 * wd)) &
+                                         (unsigned)(kGroupM - 1);
                     const volatile lds_f64* row = Tp + (((size_t)g * KT + kb) * kGroupM + nib);
                     double own = 0.0;
                     if (MINUS == 1) own = TmL[((size_t)g * KT + zoc) * kGroupM + nib];
-                    if (MINUS == 2) own = TmG[((size_t)g * KT + zoc) * kGroupM + nib];
 #pragma unroll
                     for (int c0 = 0; c0 < KH; c0 += CH) {
                         double tv[CH];
@@ -829,7 +860,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                         for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
                         if (CH < KH) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
                     }
-                    if (has_minus) acc_own = acc_own + own;
+                    if (MINUS == 1) acc_own = acc_own + own;
                 }
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_score += n_ - d_t; d_t = n_; })
                 if (!BITS && has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
@@ -936,7 +967,12 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned nibble_from_x(const int32_t* X, const uint32_t* Xb, int64_t N, int P,
                                                   int64_t i, int g) {
-    if (Xb) return (Xb[(int64_t)(g >> 3) * N + i] >> ((g & 7) * 4)) & 15u;  // bit planes: any number of words
+    if (Xb) {  // bit planes, any number of words: the field may straddle two of them
+        const int o = g * kGroupW, w = o >> 5, sh = o & 31, W = (P + 31) >> 5;
+        uint32_t v = Xb[(int64_t)w * N + i] >> sh;
+        if (sh + kGroupW > 32 && w + 1 < W) v |= Xb[(int64_t)(w + 1) * N + i] << (32 - sh);
+        return v & (unsigned)(kGroupM - 1);
+    }
     unsigned nib = 0;
 #pragma unroll
     for (int j = 0; j < kGroupW; ++j) {
