@@ -96,7 +96,7 @@ def main():
                          "(those are reported as from_random_start)")
     ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5", "ns"])
     ap.add_argument("--batch", type=int, default=0, help="observations per frozen-statistics batch (0 = default)")
-    ap.add_argument("--n", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--rows", type=int, default=0, help="override N (debug)")
     ap.add_argument("--k", type=int, default=0, help="override K (debug)")
     ap.add_argument("--x-layout", default="bits", choices=["bits", "int32"],
                     help="what the resample kernel streams: bit planes packed once at hand-over (default) "
@@ -128,9 +128,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # BMM_BENCH_REHEARSE=1: every rank on device 0 over gloo -- how the N > 1 code path (plane broadcast,
+    # per-rank seeds, max over ranks) is rehearsed on a one-GPU box; never a measurement
+    rehearse = os.environ.get("BMM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    multi.init("nccl", device=dev)
+    if rehearse:
+        multi.init("gloo")
+    else:
+        multi.init("nccl", device=dev)
 
     def barrier():
         if dist.is_initialized():
@@ -159,6 +167,7 @@ def main():
                            batch=batch_arg if batch_arg > 0 else None,
                            seed=multi.chain_seed(1000, rank * nchains + c),  # chain seeds 1000 + c
                            device=local, x_layout=x_layout) for c in range(nchains)]
+        multi.LOCAL_DEVICE = local
         ch = chains[0]
         # data: generated in HBM on rank 0 and handed to its chain; what is broadcast is the packed planes
         X = None
@@ -267,8 +276,16 @@ def main():
                         "frac": gbps / HBM_PEAK_GBS})
             return out
         vpw = info.get("valu_inst_per_64_obs")
+        # LDS traffic the scoring cannot avoid: K*G group-table reads + G own-cluster reads + K reads of the
+        # exponential's table, 8 bytes each, per observation; peak 256 B/clk/CU x 256 CUs x 2.4 GHz
+        G4 = (P + 3) // 4
+        own = 0 if m["sampler"] in ("stickbreaking", "full") else G4
+        cats = m["K"] + (1 if m["sampler"] == "dp" else 0)
+        lds_tbps = (cats * G4 + own + cats) * 8 * N * steps / secs / 1e12
+        lds_peak = 256 * 256 * 2.4e9 / 1e12
         out.update({"bound": "valu_f64_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
                     "hbm_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBS,
+                    "lds_TBps": lds_tbps, "lds_frac": lds_tbps / lds_peak,
                     "layout": "bit planes: %d bytes per observation and sweep" % (bps // N)})
         if vpw:
             ginst = vpw * (N / 64.0) * steps / secs / 1e9
@@ -276,11 +293,14 @@ def main():
                         "valu_source": info.get("source")})
         else:
             out.update({"achieved": None, "frac": None})
-        out["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 layout and is bound "
-                       "by fp64 VALU issue (K*ceil(P/4) table adds + K exponentials per observation), not by HBM: "
-                       "achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/) / launch time "
-                       "measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  hbm_frac is SURVEY.md 8d's figure "
-                       "for the bytes this layout streams; the HBM-bound kernel is other_workloads.c5_int32")
+        out["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 layout and is bound by "
+                       "what it does per observation on the CU -- K*ceil(P/4) LDS table reads + fp64 adds, K "
+                       "exponentials -- not by HBM.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, "
+                       "profiles/) / launch time measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  lds_frac is "
+                       "the same for the LDS reads the scoring cannot avoid against 256 B/clk/CU (the PMC passes "
+                       "show the LDS pipe busy 64 % and the VALU 60 % of a launch: the two limits are co-binding).  "
+                       "hbm_frac is SURVEY.md 8d's figure for the bytes this layout streams; the HBM-bound kernel is "
+                       "other_workloads.c5_int32")
         return out
 
     def cpu_leg(sampler, Xdev, K, N, batch, label):
@@ -335,7 +355,7 @@ def main():
     if args.shard:
         return bench_sharded(args, world, rank, local, dev, barrier)
     rs = 3 if (args.workload in ("c5", "ns", "c2") and args.chains_per_gpu == 1 and args.x_layout == "bits") else 0
-    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.n, args.k, args.x_layout,
+    m = measure(args.workload, args.steps, args.warmup, args.burn, args.batch, args.rows, args.k, args.x_layout,
                 nchains=args.chains_per_gpu, random_start=rs)
     sampler, K, N, P, batch = m["sampler"], m["K"], m["N"], m["P"], m["batch"]
     dt, nch = m["dt"], m["nchains"]
@@ -381,7 +401,7 @@ def main():
     del m
     # the other BASELINE points, measured in the same run (single GPU only).  Reported beside the
     # headline, never instead of it.
-    if world == 1 and not args.no_extra and args.workload == "c5" and not (args.n or args.k) and args.chains_per_gpu == 1:
+    if world == 1 and not args.no_extra and args.workload == "c5" and not (args.rows or args.k) and args.chains_per_gpu == 1:
         extra = {}
         if args.x_layout == "bits":
             # the kernel that streams the int32 matrix in place: the HBM-roofline measurement proper
@@ -450,8 +470,8 @@ def bench_sharded(args, world, rank, local, dev, barrier):
     sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
     if sampler not in ("stickbreaking", "full"):
         raise SystemExit("--shard needs a stick-breaking or full workload (e.g. --workload c4)")
-    if args.n:
-        N = args.n
+    if args.rows:
+        N = args.rows
     X, _ = synth.device_matrix(N, P, K_true, dseed, dev)      # same seed => same matrix on every rank
     lo, hi = rank * N // world, (rank + 1) * N // world
     Xl = X[:, lo:hi].contiguous()

@@ -14,6 +14,8 @@ import os
 
 import numpy as np
 
+LOCAL_DEVICE = None  # set by a caller that does not map LOCAL_RANK to the device index (bench.py's rehearsal mode)
+
 
 def world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(
@@ -70,7 +72,7 @@ def broadcast_planes(chain, X=None, src=0):
     if not multi:
         return
     ptr, n = chain.planes()
-    dev = torch.device("cuda", l) if torch.cuda.is_available() else None
+    dev = torch.device("cuda", l if LOCAL_DEVICE is None else LOCAL_DEVICE) if torch.cuda.is_available() else None
     t = device_ints(ptr, n, dev)
     dist.broadcast(t, src=src)
     torch.cuda.synchronize(dev)
