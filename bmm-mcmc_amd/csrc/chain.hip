@@ -505,8 +505,8 @@ int pick_kernel(bmm_chain* c) {
     // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
     c->OT = c->NT / split;
     const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
-    if (split == 1 && tiles < c->num_cus && c->NT > 256 && c->lds_bytes * 4 <= lds_max && minus != 2 &&
-        !dbg_env("BMM_DEBUG_THREADS")) {
+    if (split == 1 && tiles < c->num_cus && c->NT > 256 && (c->lds_bytes * 4 <= lds_max || dbg_env("BMM_DEBUG_SMALL")) &&
+        minus != 2 && !dbg_env("BMM_DEBUG_THREADS")) {
         resample_fn f = resample_kernel_small_of(p.KT, minus, c->bits);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
         int pc2 = 0;

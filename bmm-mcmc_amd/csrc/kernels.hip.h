@@ -95,6 +95,32 @@ __device__ __forceinline__ void delta_clear(int32_t* d, size_t idx, size_t strid
     for (int r = 0; r < kDeltaReps; ++r) d[idx + r * stride] = 0;
 }
 
+// update_alpha_ (bmm_spec.h) with its four gamma variates -- independent Philox streams by construction --
+// drawn by lanes 0..3 of one wave side by side instead of one after the other (each is a rejection loop
+// of logs and square roots: about 1.5 us of latency apiece for a single lane); lane 0 combines them with
+// the very operations of the serial form, so the result is bit-identical.  Call with the whole wave;
+// the value is valid on lane 0.
+__device__ __forceinline__ double update_alpha_wave(double alpha_old, double a, double b, double N, int K,
+                                                    uint64_t seed, uint32_t sweep, int lane) {
+    double g = 0.0;
+    if (lane < 4) {
+        const double shape = lane == 0 ? alpha_old + 1.0 : (lane == 1 ? N : (lane == 2 ? a + (double)K : a + (double)K - 1.0));
+        Stream st = make_stream(seed, lane == 1 ? 1u : 0u, sweep,
+                                lane < 2 ? kStreamAlphaEta : (lane == 2 ? kStreamAlphaG1 : kStreamAlphaG2));
+        g = rgamma_(shape, st);
+    }
+    const double x = __shfl(g, 0), y = __shfl(g, 1), g1 = __shfl(g, 2), g2 = __shfl(g, 3);
+    const double eta = div_(x, x + y);  // rbeta_
+    const double b_eps = b - log_(eta);
+    const double pi1 = a + (double)K - 1.0;
+    const double pi2 = N * b_eps;
+    const double pi = div_(pi1, pi1 + pi2);
+    const double scale = div_(1.0, b_eps);
+    const double ga = g1 * scale;
+    const double gb = g2 * scale;
+    return pi * ga + (1.0 - pi) * gb;
+}
+
 // ---------------------------------------------------------------------------------
 // Table construction: one workgroup per category.  For the counting samplers it first
 // folds the pending integer deltas of its cluster into the statistics.
@@ -259,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_sb_params(ChainParams p, int32_t* __re
                                                    int32_t* __restrict__ nk_trace) {
     __shared__ int32_t ck[kMaxCatsAny];
     __shared__ double v[kMaxCatsAny];
+    __shared__ int sh_viable;
     const int K = p.K, P = p.P;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + delta_take(dNk, k, K);
@@ -310,12 +337,17 @@ __global__ __launch_bounds__(1024) void k_sb_params(ChainParams p, int32_t* __re
                 if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
             }
         }
+        sh_viable = viable;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // the concentration: four gammas side by side (update_alpha_wave)
         double alpha_new = alpha_prev;
-        if (p.sample_alpha) {
-            alpha_new = update_alpha_(alpha_prev, p.a, p.b, (double)p.Ntot, viable, p.seed, sweep);
-            *alpha_ptr = alpha_new;
+        if (p.sample_alpha)
+            alpha_new = update_alpha_wave(alpha_prev, p.a, p.b, (double)p.Ntot, sh_viable, p.seed, sweep, threadIdx.x);
+        if (threadIdx.x == 0) {
+            if (p.sample_alpha) *alpha_ptr = alpha_new;
+            if (alpha_trace) *alpha_trace = alpha_new;
         }
-        if (alpha_trace) *alpha_trace = alpha_new;
     }
 }
 
@@ -365,15 +397,17 @@ __global__ __launch_bounds__(1024) void k_count_sweep_end(ChainParams p, int32_t
             theta_trace[k + d * K] = t;
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {  // the first wave: the concentration, four gammas side by side
         double al = *alpha_ptr;
         if (p.sample_alpha) {
             int Kc = K;
             if (p.mode == MODE_DP) { Kc = 0; for (int k = 0; k < K; ++k) Kc += nk[k] > 0; }
-            al = update_alpha_(al, p.a, p.b, (double)p.Ntot, Kc, p.seed, sweep);
-            *alpha_ptr = al;
+            al = update_alpha_wave(al, p.a, p.b, (double)p.Ntot, Kc, p.seed, sweep, threadIdx.x);
         }
-        if (alpha_trace) *alpha_trace = al;
+        if (threadIdx.x == 0) {
+            if (p.sample_alpha) *alpha_ptr = al;
+            if (alpha_trace) *alpha_trace = al;
+        }
     }
 }
 
