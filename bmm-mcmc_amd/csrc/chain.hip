@@ -129,7 +129,7 @@ resample_fn resample_kernel_small(int kt) {
 // small to give every CU one of the default-sized workgroups, and by BMM_DEBUG_THREADS
 template <int NT, int MINUS, bool BITS>
 resample_fn resample_kernel_nt(int kt) {
-    constexpr int SW = BITS ? 16 : kStageWide;
+    constexpr int SW = BITS || NT == 1024 ? 16 : kStageWide;  // 1024 threads: 128 VGPRs, 16 loads in flight per wave
     switch (kt) {
         case 4: return k_resample<4, NT, MINUS, SW, BITS>;
         case 8: return k_resample<8, NT, MINUS, SW, BITS>;
@@ -151,6 +151,7 @@ resample_fn resample_kernel_at(int kt, int nt, int minus, bool bits) {
         return nullptr;
     }
     if (kt > 20 || minus != 1) return nullptr;
+    if (nt == 1024) return resample_kernel_nt<1024, 1, false>(kt);
     if (nt == 768) return resample_kernel_nt<768, 1, false>(kt);
     if (nt == 512) return resample_kernel_nt<512, 1, false>(kt);
     return nullptr;
@@ -282,12 +283,14 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
 }
 
 // A pure function of (sampler, N) -- no device, occupancy or layout enters, so a defaulted batch
-// names the same chain everywhere.  Above 2^18 observations (one round of 256 workgroups of 1024
-// on an MI355X) it is rounded up to whole multiples of that, so that the big shapes run whole rounds.
+// names the same chain everywhere.  Above 3 * 2^18 observations it is rounded up to whole multiples of
+// that: 256 workgroups x 3072 observations, i.e. whole rounds of the chip for 1024-, 768- and
+// 512-thread workgroups alike (a multiple of 2^18 alone leaves the 768-thread kernels of the int32
+// layout with 6.67 chunks per wave: one ragged round in seven).
 int64_t default_batch(int sampler, int64_t N) {
     if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
     int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
-    const int64_t round = (int64_t)1 << 18;
+    const int64_t round = (int64_t)3 << 18;
     if (b > round) b = (b + round - 1) / round * round;
     if (b > N) b = N;
     return b < 1 ? 1 : b;
@@ -1252,8 +1255,10 @@ int rccl_broadcast_words(const std::vector<int>& devs, const std::vector<void*>&
     }
     if (he == hipSuccess) {
         e = r.GroupStart();
+        // every rank passes its own buffer, in place (the root's holds the data; a send buffer is read
+        // on the root only, and a pointer of another device must not be handed to a rank's call)
         for (int q = 0; q < n && e == ncclSuccess; ++q)
-            e = r.Broadcast(bufs[0], bufs[(size_t)q], count, ncclUint32, 0, comms[(size_t)q], st[(size_t)q]);
+            e = r.Broadcast(bufs[(size_t)q], bufs[(size_t)q], count, ncclUint32, 0, comms[(size_t)q], st[(size_t)q]);
         const ncclResult_t e2 = r.GroupEnd();
         if (e == ncclSuccess) e = e2;
         for (int q = 0; q < n && he == hipSuccess; ++q) {

@@ -80,7 +80,10 @@ struct ChainParams {
 // launch every workgroup flushes its histogram at the same moment, and device-scope atomics on one
 // word serialise (about 12 ns each), so 250 workgroups on the same 1-2 k words cost microseconds;
 // eight replicas cut the queue per word eightfold.  Consumers sum (and clear) the replicas.
-constexpr int kDeltaReps = 8;
+#ifndef BMM_DELTA_REPS
+#define BMM_DELTA_REPS 8
+#endif
+constexpr int kDeltaReps = BMM_DELTA_REPS;
 __device__ __forceinline__ int32_t delta_take(int32_t* d, size_t idx, size_t stride) {
     int32_t v[kDeltaReps];
 #pragma unroll

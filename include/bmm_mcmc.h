@@ -77,8 +77,9 @@ const char* bmm_last_error(void);
 /* features per lookup group of the spec arithmetic (DESIGN.md "Numerics") */
 int bmm_spec_group_width(void);
 /* library default batch size for N observations (used when batch <= 0): N/8 for the finite
- * sampler, N/16 for the DP sampler (rounded up to a multiple of 2^18 above that), N for
- * stick-breaking and full; depends on nothing else.  See DESIGN.md "Batches" */
+ * sampler, N/16 for the DP sampler (rounded up to a multiple of 3 * 2^18 above that: whole rounds of
+ * 256 workgroups of 1024, 768 or 512 threads), N for stick-breaking and full; depends on nothing
+ * else.  See DESIGN.md "Batches" */
 int64_t bmm_default_batch(int sampler, int64_t N);
 
 /* ---- drop-in entry points --------------------------------------------------------

@@ -35,8 +35,9 @@ def test_spec_constants_match_oracle(oracle):
 def test_default_batch_policy():
     assert bm.default_batch("stickbreaking", 1000) == 1000
     assert bm.default_batch("collapsed", 100) == 12
-    # a pure function of (sampler, N): N/8 (N/16 dp), in whole multiples of 2^18 above that
-    assert bm.default_batch("collapsed", 10 ** 7) == 5 * 2 ** 18
+    # a pure function of (sampler, N): N/8 (N/16 dp), in whole multiples of 3 * 2^18 above that
+    assert bm.default_batch("collapsed", 10 ** 7) == 2 * 3 * 2 ** 18
+    assert bm.default_batch("collapsed", 8 * 3 * 2 ** 18) == 3 * 2 ** 18
     assert bm.default_batch("collapsed", 10 ** 6) == 125000
     assert bm.default_batch("dp", 10 ** 6) == 62500
     assert bm.default_batch("dp", 1600) == 100
