@@ -366,8 +366,8 @@ class Chain:
         _capi.check(_capi.lib().bmm_chain_set_data_device(self._h, _C.c_void_p(int(ptr))))
 
     def share_data(self, other):
-        """Borrow the bit planes `other` (same device, N, P) already holds: several chains over one copy."""
-        self._keep = other
+        """Share the bit planes `other` (same device, N, P) already holds: several chains over one copy
+        (reference-counted in the library: chains may be closed in any order)."""
         _capi.check(_capi.lib().bmm_chain_share_data(self._h, other._h))
 
     def planes(self):

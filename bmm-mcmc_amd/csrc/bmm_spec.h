@@ -37,7 +37,7 @@ constexpr int kGroupM = 1 << kGroupW;  // entries per group table
 
 // Philox stream ids (counter word 3)
 enum : uint32_t {
-    kStreamZ = 0,        // c0,c1 = observation index, c2 = sweep
+    kStreamZ = 0,        // (reserved: the per-observation uniform is Philox2x32 under its own key, z_uniform)
     kStreamStickA = 1,   // v_k ~ Beta: first gamma;  c0 = k, c1 = block counter, c2 = sweep
     kStreamStickB = 2,   // v_k ~ Beta: second gamma
     kStreamThetaA = 3,   // theta_kd ~ Beta: first gamma; c0 = k*P+d

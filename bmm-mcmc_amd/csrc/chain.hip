@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <string>
 #include <thread>
@@ -233,7 +234,11 @@ struct bmm_chain {
     const int32_t* dX = nullptr;
     int32_t* dX_owned = nullptr;
     uint32_t* dXb = nullptr;      // bit planes of X (k_pack_bits), what the resident kernels stream by default
-    bool xb_borrowed = false;     // dXb belongs to another chain on this device (bmm_chain_share_data)
+    // the planes are shared by reference count between the chains of a device that run over the same data
+    // (bmm_chain_share_data): the last chain to go frees them, in whatever order chains are destroyed
+    struct Planes { uint32_t* d = nullptr; std::atomic<int> refs{1}; };
+    Planes* planes = nullptr;
+    bool xb_borrowed = false;     // this chain took its planes from another one
     bool bits = false;
     int num_cus = 0;
     int32_t* dZ[2] = {nullptr, nullptr};
@@ -259,10 +264,16 @@ struct bmm_chain {
 
 namespace {
 
-// Default batch (profiles/r01/batch_bias_oracle.json): the finite sampler's posterior is
-// within seed noise of the sequential scan up to about N/8 on the hardest bundled data set
-// (no measurable shift at any batch on well-separated data); the DP sampler opens spurious
-// clusters above about N/16, because every "new" draw of a batch shares one label.
+int planes_alloc(bmm_chain* c, size_t words) {
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc(&d, words * sizeof(uint32_t)));
+    c->planes = new (std::nothrow) bmm_chain::Planes();
+    if (!c->planes) { (void)hipFree(d); return set_err(BMM_E_ARG, "out of host memory"); }
+    c->planes->d = d;
+    c->dXb = d;
+    return BMM_OK;
+}
+
 // every cell of X must be 0 or 1: one streaming pass when the matrix is handed over
 int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
     DevBuf flagbuf;
@@ -282,6 +293,9 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
     return BMM_OK;
 }
 
+// Default batch: N/8 for the finite sampler, N/16 for the DP sampler (above that every "new" draw of a
+// batch shares one label and spurious clusters open); the stated tolerance against the sequential scan
+// is in include/bmm_mcmc.h, the measurements behind it in DESIGN.md section 2.
 // A pure function of (sampler, N) -- no device, occupancy or layout enters, so a defaulted batch
 // names the same chain everywhere.  Above 3 * 2^18 observations it is rounded up to whole multiples of
 // that: 256 workgroups x 3072 observations, i.e. whole rounds of the chip for 1024-, 768- and
@@ -667,7 +681,11 @@ void bmm_chain_destroy(bmm_chain* c) {
     }
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    void* bufs[] = {c->dX_owned, c->xb_borrowed ? nullptr : c->dXb, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk,
+    if (c->planes && c->planes->refs.fetch_sub(1) == 1) {  // the last chain over these planes
+        (void)hipFree(c->planes->d);
+        delete c->planes;
+    }
+    void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk,
                     c->dDS, c->dAlpha, c->dTab, c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace,
                     c->dPiTrace, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
@@ -721,7 +739,7 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
     // bit planes: the int32 matrix passes through a staging buffer in slabs of rows (<= 256 MiB) and
     // never exists whole on the device -- 16 bytes per observation stay instead of 4 P
     const int W = (P + 31) / 32;
-    if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * N * sizeof(uint32_t)));
+    if (!c->dXb) { int rcp = planes_alloc(c, (size_t)W * N); if (rcp) return rcp; }
     int64_t slab = ((int64_t)256 << 20) / ((int64_t)P * 4);
     slab = slab / 4 * 4;
     if (slab < 4) slab = 4;
@@ -764,7 +782,7 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
     if (rc) return rc;
     if (c->bits) {  // packed here and now; the caller's matrix is not read again
         const int W = (c->p.P + 31) / 32;
-        if (!c->dXb) HIP_TRY(hipMalloc(&c->dXb, (size_t)W * c->p.N * sizeof(uint32_t)));
+        if (!c->dXb) { rc = planes_alloc(c, (size_t)W * c->p.N); if (rc) return rc; }
         rc = pack_rows(c, x, c->p.N, c->p.N, 0);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -784,6 +802,8 @@ int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from) {
     if (from->device != c->device) return set_err(BMM_E_ARG, "chains on different devices cannot share planes");
     if (from->p.N != c->p.N || from->p.P != c->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
     if (!c->bits) return set_err(BMM_E_STATE, "the int32 layout streams the caller's matrix: hand it over instead");
+    c->planes = from->planes;
+    c->planes->refs.fetch_add(1);
     c->dXb = from->dXb;
     c->xb_borrowed = true;
     c->dX = nullptr;
@@ -798,7 +818,8 @@ int bmm_chain_planes(bmm_chain* c, void** dXb, int64_t* n_words) {
     const int64_t words = (int64_t)((c->p.P + 31) / 32) * c->p.N;
     if (!c->dXb) {
         if (c->started) return set_err(BMM_E_STATE, "chain already started");
-        HIP_TRY(hipMalloc(&c->dXb, (size_t)words * sizeof(uint32_t)));
+        int rcp = planes_alloc(c, (size_t)words);
+        if (rcp) return rcp;
     }
     *dXb = c->dXb;
     if (n_words) *n_words = words;
@@ -1376,9 +1397,7 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
     std::vector<bmm_chain*> chains((size_t)n_chains, nullptr);
     struct Guard {
         std::vector<bmm_chain*>& v;
-        // borrowers first: a chain that lent its planes must outlive them
-        ~Guard() { for (bmm_chain* c : v) if (c && c->xb_borrowed) bmm_chain_destroy(c);
-                   for (bmm_chain* c : v) if (c && !c->xb_borrowed) bmm_chain_destroy(c); }
+        ~Guard() { for (bmm_chain* c : v) bmm_chain_destroy(c); }  // shared planes go with their last chain
     } guard{chains};
     int rc = BMM_OK;
     for (int c = 0; c < n_chains && rc == BMM_OK; ++c) {

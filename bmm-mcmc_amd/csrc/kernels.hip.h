@@ -1,15 +1,17 @@
 // kernels.hip.h -- gfx950 kernels of the cluster-allocation path.
 //
-// One observation per lane (wave64).  The N x P data matrix is read in the layout R
-// hands over (int32, column-major): lane i reads X[i + d*N], so a wave reads 256
-// contiguous bytes per feature.  Features are packed to bits in registers as they
-// arrive; the per-cluster log-predictive is then K*ceil(P/4) LDS lookups into
-// 16-entry group tables (one ds_read_b64 + one v_add_f64 per cluster per 4 features)
-// instead of K*P multiply-adds.  All 16 entries of a group sit in one 128-byte run,
-// i.e. on 16 different bank pairs, so the per-lane-indexed read is conflict-free.
-// Sufficient-statistic changes are accumulated as integers in LDS (wave-cooperative:
-// one mover at a time, one feature per lane) and flushed with one global integer
-// atomic per touched cell per workgroup -- order-independent, hence deterministic.
+// One observation per lane (wave64).  X is streamed either as bit planes packed once when the
+// matrix is handed over (ceil(P/32) 32-bit words per observation; the default) or as the N x P
+// int32 column-major matrix R hands over (lane i reads X[i + d*N]: a wave reads 256 contiguous
+// bytes per feature, packed to bits in registers as they arrive).  The per-cluster log-predictive
+// is K*ceil(P/4) LDS lookups into 16-entry group tables (one ds_read_b64 + one v_add_f64 per
+// cluster per 4 features; the category's constant term sits in group 0) instead of K*P
+// multiply-adds.  All 16 entries of a group sit in one 128-byte run, i.e. on 16 different bank
+// pairs, so the per-lane-indexed read is conflict-free.  Work is handed out per wave in chunks of 64
+// observations from a counter in LDS.  Sufficient-statistic changes are accumulated as integers in
+// LDS (a few movers: one at a time by the whole wave, one feature per lane; many: every mover lane
+// walks its own set bits) and flushed with one global integer atomic per touched cell per
+// workgroup -- order-independent, hence deterministic.
 //
 // Reference lines realised here (all /root/reference/src):
 //   z | rest, finite K      collapsed_gibbs.cpp:86-182
@@ -1002,7 +1004,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 // scr[k * stride + thread].  Clusters are accumulated sixteen at a time, X is re-read per chunk.
 // Slow next to the resident kernel; it exists so that every shape the reference accepts runs.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned nibble_from_x(const int32_t* X, const uint32_t* Xb, int64_t N, int P,
+__device__ __forceinline__ unsigned field_from_x(const int32_t* X, const uint32_t* Xb, int64_t N, int P,
                                                   int64_t i, int g) {
     if (Xb) {  // bit planes, any number of words: the field may straddle two of them
         const int o = g * kGroupW, w = o >> 5, sh = o & 31, W = (P + 31) >> 5;
@@ -1044,14 +1046,14 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
         double acc_own = 0.0;
         if (has_minus)
             for (int g = 0; g < G; ++g)
-                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + nibble_from_x(a.X, a.Xb, p.N, P, i, g)];
+                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + field_from_x(a.X, a.Xb, p.N, P, i, g)];
         double m = neg_inf();
         for (int k0 = 0; k0 < Kc; k0 += 16) {
             double acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
             for (int g = 0; g < G; ++g) {
-                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + nibble_from_x(a.X, a.Xb, p.N, P, i, g);
+                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + field_from_x(a.X, a.Xb, p.N, P, i, g);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (k0 + j < Kc) acc[j] = acc[j] + row[j * kGroupM];

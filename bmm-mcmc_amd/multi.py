@@ -68,14 +68,18 @@ def broadcast_planes(chain, X=None, src=0):
     if not multi or r == src:
         if X is None:
             raise ValueError("the source rank needs the matrix")
-        chain.set_data_device(X.data_ptr(), keepalive=None)   # packed now; X is not read again
+        chain.set_data_device(X.data_ptr(), keepalive=X if hasattr(chain, "planes_tensor") else None)  # packed now
     if not multi:
         return
-    ptr, n = chain.planes()
-    dev = torch.device("cuda", l if LOCAL_DEVICE is None else LOCAL_DEVICE) if torch.cuda.is_available() else None
-    t = device_ints(ptr, n, dev)
+    if hasattr(chain, "planes_tensor"):       # a stand-in chain of the CPU tests hands over its own tensor
+        t, dev = chain.planes_tensor(), None
+    else:
+        ptr, n = chain.planes()
+        dev = torch.device("cuda", l if LOCAL_DEVICE is None else LOCAL_DEVICE)
+        t = device_ints(ptr, n, dev)
     dist.broadcast(t, src=src)
-    torch.cuda.synchronize(dev)
+    if dev is not None:
+        torch.cuda.synchronize(dev)
     if r != src:
         chain.planes_filled()
 

@@ -200,8 +200,9 @@ int bmm_chain_get_x_layout(const bmm_chain* c, int* layout);
  * is complete before it is validated and packed. */
 int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X);
 int bmm_chain_set_data_device(bmm_chain* c, const void* dX);
-/* Several chains on one device over the same data: `c` borrows the bit planes `from` holds (same
- * device, N and P; `from` must outlive `c`).  What bmm_multi_run does for chains that share a device. */
+/* Several chains on one device over the same data: `c` shares the bit planes `from` holds (same
+ * device, N and P).  The planes are reference-counted: chains may be destroyed in any order, the last
+ * one frees them.  What bmm_multi_run does for chains that share a device. */
 int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from);
 /* The chain's bit planes on its device: ceil(P/32) planes of N 32-bit words (allocated on first
  * call).  A rank that received them from a broadcast (160 MB instead of the 4 GB int32 matrix at

@@ -86,8 +86,15 @@ def test_resident_chains_sharing_planes_and_swept_together(oracle):
             assert c.alpha() == want["alpha"][0, 0]
         with pytest.raises(bm.BmmError, match="already has its data"):
             chains[1].share_data(chains[0])
+        # the planes are reference-counted: the chain that packed them may go first
+        chains[0].close()
+        bm.sweep_chains(chains[1:], 2)
+        for c in chains[1:]:
+            c.sync()
+        want = oracle.collapsed(X, z0s[3], 8, K, 0.0, 0.5, 0.5, 1, 1, 7, seed=903, batch=2500)
+        assert np.array_equal(chains[3].labels(), want["z"][0])
     finally:
-        for c in chains[1:] + chains[:1]:   # borrowers first
+        for c in chains:
             c.close()
 
 

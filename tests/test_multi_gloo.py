@@ -29,6 +29,32 @@ def _oracle_chain(sampler, X, K, nsweeps, seed, batch, **prior):
     return r["z"][0]
 
 
+class _PlanesStub:
+    """Stand-in for bmm_mcmc_amd.Chain in the plane broadcast (no GPU here): packs the (P, N) int32 matrix it
+    is handed into ceil(P/32) words per observation, exactly the layout k_pack_bits writes."""
+
+    def __init__(self, P, N):
+        self.P, self.N = P, N
+        self.W = (P + 31) // 32
+        self.t = torch.zeros(self.W * N, dtype=torch.int32)
+        self.saw_matrix = False
+        self.filled = False
+
+    def set_data_device(self, ptr, keepalive=None):
+        X = keepalive.numpy().astype(np.uint32)                # (P, N)
+        self.saw_matrix = True
+        words = np.zeros((self.W, self.N), dtype=np.uint32)
+        for d in range(self.P):
+            words[d // 32] |= (X[d] & 1) << np.uint32(d % 32)
+        self.t.copy_(torch.from_numpy(words.view(np.int32).reshape(-1)))
+
+    def planes_tensor(self):
+        return self.t
+
+    def planes_filled(self):
+        self.filled = True
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -45,10 +71,15 @@ def _worker(rank, world, port, q):
     else:
         X = torch.zeros((P, N), dtype=torch.int32)
     multi.broadcast_data(X, src=0)
+    # the collective bench.py and the multi-GPU launcher use: rank 0 packs, the planes travel, nobody else
+    # ever holds the matrix
+    stub = _PlanesStub(P, N)
+    multi.broadcast_planes(stub, X if rank == 0 else None, src=0)
+    planes = (int(stub.t.to(torch.int64).sum()), stub.saw_matrix, stub.filled)
     z, summ = multi.run_chains("collapsed", X, K, 30, base_seed=1000, batch=64, run_fn=_oracle_chain)
     z_same, _ = multi.run_chains("collapsed", X, K, 30, base_seed=1000, batch=64, run_fn=_oracle_chain)
     mx = multi.max_over_ranks(1.0 + rank)
-    q.put((rank, int(X.sum()), z.tolist(), z_same.tolist(), summ.tolist(), mx, multi.chain_seed(1000, rank)))
+    q.put((rank, int(X.sum()), z.tolist(), z_same.tolist(), summ.tolist(), mx, multi.chain_seed(1000, rank), planes))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -65,7 +96,10 @@ def test_two_ranks_broadcast_seed_and_gather(oracle):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, sum0, z0, z0b, summ0, mx0, seed0), (r1, sum1, z1, z1b, summ1, mx1, seed1) = got
+    (r0, sum0, z0, z0b, summ0, mx0, seed0, pl0), (r1, sum1, z1, z1b, summ1, mx1, seed1, pl1) = got
+    assert pl0[0] == pl1[0] != 0                # both ranks hold the same bit planes
+    assert pl0[1:] == (True, False)             # rank 0 packed the matrix it generated
+    assert pl1[1:] == (False, True)             # rank 1 received planes only and declared them filled
     assert sum0 == sum1 and sum0 > 0            # every rank holds the broadcast matrix
     assert (seed0, seed1) == (1000, 1001)       # chain c runs under key base + c
     assert z0 == z0b and z1 == z1b              # same seed -> same chain
