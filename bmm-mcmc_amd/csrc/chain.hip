@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <new>
 #include <string>
 #include <thread>
@@ -62,6 +63,27 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// No C++ exception may cross the C ABI: the entry points that allocate on the host or start threads run
+// their bodies through this.
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return set_err(BMM_E_ARG, "out of host memory");
+    } catch (const std::exception& e) {
+        return set_err(BMM_E_STATE, "unexpected host error: %s", e.what());
+    } catch (...) {
+        return set_err(BMM_E_STATE, "unexpected host error");
+    }
+}
+// host threads that are always joined, also when starting a later one throws
+struct ThreadGroup {
+    std::vector<std::thread> th;
+    ~ThreadGroup() { join(); }
+    void join() { for (std::thread& t : th) if (t.joinable()) t.join(); }
 };
 
 // accumulator counts the resample kernel is instantiated for
@@ -838,19 +860,21 @@ int bmm_chain_planes_filled(bmm_chain* c) {
 }
 
 int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1) {
-    if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
-    if (c->p.mode != MODE_COLLAPSED) return set_err(BMM_E_STATE, "only the finite collapsed sampler takes initial labels");
-    if (c->started) return set_err(BMM_E_STATE, "chain already started");
-    std::vector<int32_t> z0((size_t)c->p.N);
-    for (int64_t i = 0; i < c->p.N; ++i) {
-        if (z1[i] < 1 || z1[i] > c->p.K) return set_err(BMM_E_ARG, "initialK[%lld] = %d outside 1..%d", (long long)i, z1[i], c->p.K);
-        z0[(size_t)i] = z1[i] - 1;
-    }
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->dZ[0], z0.data(), z0.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->have_init = true;
-    return BMM_OK;
+    return guarded([&]() -> int {
+        if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
+        if (c->p.mode != MODE_COLLAPSED) return set_err(BMM_E_STATE, "only the finite collapsed sampler takes initial labels");
+        if (c->started) return set_err(BMM_E_STATE, "chain already started");
+        std::vector<int32_t> z0((size_t)c->p.N);
+        for (int64_t i = 0; i < c->p.N; ++i) {
+            if (z1[i] < 1 || z1[i] > c->p.K) return set_err(BMM_E_ARG, "initialK[%lld] = %d outside 1..%d", (long long)i, z1[i], c->p.K);
+            z0[(size_t)i] = z1[i] - 1;
+        }
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpyAsync(c->dZ[0], z0.data(), z0.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_init = true;
+        return BMM_OK;
+    });
 }
 
 int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* theta) {
@@ -866,20 +890,22 @@ int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* t
 }
 
 int bmm_chain_sweeps(bmm_chain* c, int n) {
-    if (!c) return set_err(BMM_E_ARG, "null chain");
-    if (n < 0) return set_err(BMM_E_ARG, "n must be >= 0");
-    if (c->sharded && n > 0) return set_err(BMM_E_STATE, "a sharded chain advances by bmm_chain_shard_resample / _finish");
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->started) {
-        int rc = chain_start(c);
-        if (rc) return rc;
-    }
-    for (int t = 0; t < n; ++t) {
-        int rc = enqueue_sweep(c, c->sweep + 1);
-        if (rc) return rc;
-        c->sweep++;
-    }
-    return BMM_OK;
+    return guarded([&]() -> int {
+        if (!c) return set_err(BMM_E_ARG, "null chain");
+        if (n < 0) return set_err(BMM_E_ARG, "n must be >= 0");
+        if (c->sharded && n > 0) return set_err(BMM_E_STATE, "a sharded chain advances by bmm_chain_shard_resample / _finish");
+        HIP_TRY(hipSetDevice(c->device));
+        if (!c->started) {
+            int rc = chain_start(c);
+            if (rc) return rc;
+        }
+        for (int t = 0; t < n; ++t) {
+            int rc = enqueue_sweep(c, c->sweep + 1);
+            if (rc) return rc;
+            c->sweep++;
+        }
+        return BMM_OK;
+    });
 }
 
 int bmm_chain_set_shard(bmm_chain* c, int64_t N_total, int64_t first_row) {
@@ -999,21 +1025,23 @@ int bmm_chain_get_labels(bmm_chain* c, int32_t* z1) {
 }
 
 int bmm_chain_get_counts(bmm_chain* c, int32_t* Nk, int32_t* S) {
-    if (!c || !Nk || !S) return set_err(BMM_E_ARG, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = launch_reduce_deltas(c);
-    if (rc) return rc;
-    rc = bmm_chain_sync(c);
-    if (rc) return rc;
-    const size_t K = (size_t)c->p.K, KP = K * c->p.P;
-    std::vector<int32_t> d(KP > K ? KP : K);
-    HIP_TRY(hipMemcpy(Nk, c->dNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(d.data(), c->dDNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < K; ++k) Nk[k] += d[k];
-    HIP_TRY(hipMemcpy(S, c->dS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(d.data(), c->dDS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < KP; ++q) S[q] += d[q];
-    return BMM_OK;
+    return guarded([&]() -> int {
+        if (!c || !Nk || !S) return set_err(BMM_E_ARG, "null argument");
+        HIP_TRY(hipSetDevice(c->device));
+        int rc = launch_reduce_deltas(c);
+        if (rc) return rc;
+        rc = bmm_chain_sync(c);
+        if (rc) return rc;
+        const size_t K = (size_t)c->p.K, KP = K * c->p.P;
+        std::vector<int32_t> d(KP > K ? KP : K);
+        HIP_TRY(hipMemcpy(Nk, c->dNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.data(), c->dDNk, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < K; ++k) Nk[k] += d[k];
+        HIP_TRY(hipMemcpy(S, c->dS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d.data(), c->dDS, KP * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < KP; ++q) S[q] += d[q];
+        return BMM_OK;
+    });
 }
 
 int bmm_chain_get_alpha(bmm_chain* c, double* alpha) {
@@ -1216,17 +1244,19 @@ int check_run_args(const int32_t* X, int nsamples, int burnin, const RunIO& io, 
 int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int K, double alpha, double beta,
               double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed, int device,
               const RunIO& io, const bmm_relabel_hooks* hooks) {
-    int rc = check_run_args(X, nsamples, burnin, io, sampler);
-    if (rc) return rc;
-    bmm_chain* c = nullptr;
-    rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
-    if (rc) return rc;
-    struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
-    rc = run_prepare(c, nsamples, burnin);
-    if (rc) return rc;
-    rc = bmm_chain_set_data_host(c, X);
-    if (rc) return rc;
-    return run_body(c, nsamples, io, hooks);
+    return guarded([&]() -> int {
+        int rc = check_run_args(X, nsamples, burnin, io, sampler);
+        if (rc) return rc;
+        bmm_chain* c = nullptr;
+        rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
+        if (rc) return rc;
+        struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
+        rc = run_prepare(c, nsamples, burnin);
+        if (rc) return rc;
+        rc = bmm_chain_set_data_host(c, X);
+        if (rc) return rc;
+        return run_body(c, nsamples, io, hooks);
+    });
 }
 
 // ---- RCCL, opened on demand: only a run that spans devices needs it, and a process that has
@@ -1371,147 +1401,153 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
                   double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed,
                   double* const* pi_out, int32_t* const* z_out, double* const* theta_out,
                   double* const* alpha_out) {
-    if (sampler < 0 || sampler > 3) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
-    if (n_chains < 1) return set_err(BMM_E_ARG, "n_chains must be >= 1");
-    if (!z_out || !theta_out || !alpha_out) return set_err(BMM_E_ARG, "null output table");
-    if (sampler == BMM_SAMPLER_COLLAPSED && !initialK) return set_err(BMM_E_ARG, "initialK is null");
-    if (explicit_params(sampler) && (!initialPi || !initialTheta || !pi_out)) return set_err(BMM_E_ARG, "null buffer table");
-    std::vector<RunIO> io((size_t)n_chains);
-    for (int c = 0; c < n_chains; ++c) {
-        RunIO& q = io[(size_t)c];
-        if (sampler == BMM_SAMPLER_COLLAPSED) q.z0 = initialK[c];
-        if (explicit_params(sampler)) { q.pi0 = initialPi[c]; q.theta0 = initialTheta[c]; q.pi_out = pi_out[c]; }
-        q.z_out = z_out[c]; q.theta_out = theta_out[c]; q.alpha_out = alpha_out[c];
-        int rc = check_run_args(X, nsamples, burnin, q, sampler);
+    return guarded([&]() -> int {
+        if (sampler < 0 || sampler > 3) return set_err(BMM_E_ARG, "unknown sampler %d", sampler);
+        if (n_chains < 1) return set_err(BMM_E_ARG, "n_chains must be >= 1");
+        if (!z_out || !theta_out || !alpha_out) return set_err(BMM_E_ARG, "null output table");
+        if (sampler == BMM_SAMPLER_COLLAPSED && !initialK) return set_err(BMM_E_ARG, "initialK is null");
+        if (explicit_params(sampler) && (!initialPi || !initialTheta || !pi_out)) return set_err(BMM_E_ARG, "null buffer table");
+        std::vector<RunIO> io((size_t)n_chains);
+        for (int c = 0; c < n_chains; ++c) {
+            RunIO& q = io[(size_t)c];
+            if (sampler == BMM_SAMPLER_COLLAPSED) q.z0 = initialK[c];
+            if (explicit_params(sampler)) { q.pi0 = initialPi[c]; q.theta0 = initialTheta[c]; q.pi_out = pi_out[c]; }
+            q.z_out = z_out[c]; q.theta_out = theta_out[c]; q.alpha_out = alpha_out[c];
+            int rc = check_run_args(X, nsamples, burnin, q, sampler);
+            if (rc) return rc;
+        }
+        // chain c lives on devices[c] (device 0 when the table is null); distinct devices in first-use order
+        std::vector<int> dev_of((size_t)n_chains), devs;
+        for (int c = 0; c < n_chains; ++c) {
+            const int d = devices ? devices[c] : 0;
+            dev_of[(size_t)c] = d;
+            bool seen = false;
+            for (int e : devs) seen = seen || e == d;
+            if (!seen) devs.push_back(d);
+        }
+        std::vector<bmm_chain*> chains((size_t)n_chains, nullptr);
+        struct Guard {
+            std::vector<bmm_chain*>& v;
+            ~Guard() { for (bmm_chain* c : v) bmm_chain_destroy(c); }  // shared planes go with their last chain
+        } guard{chains};
+        int rc = BMM_OK;
+        for (int c = 0; c < n_chains && rc == BMM_OK; ++c) {
+            rc = bmm_chain_create(&chains[(size_t)c], sampler, N, P, K, alpha, beta, gamma, a, b, batch,
+                                  seed + (uint64_t)c, dev_of[(size_t)c]);
+            if (rc == BMM_OK) rc = run_prepare(chains[(size_t)c], nsamples, burnin);
+        }
         if (rc) return rc;
-    }
-    // chain c lives on devices[c] (device 0 when the table is null); distinct devices in first-use order
-    std::vector<int> dev_of((size_t)n_chains), devs;
-    for (int c = 0; c < n_chains; ++c) {
-        const int d = devices ? devices[c] : 0;
-        dev_of[(size_t)c] = d;
-        bool seen = false;
-        for (int e : devs) seen = seen || e == d;
-        if (!seen) devs.push_back(d);
-    }
-    std::vector<bmm_chain*> chains((size_t)n_chains, nullptr);
-    struct Guard {
-        std::vector<bmm_chain*>& v;
-        ~Guard() { for (bmm_chain* c : v) bmm_chain_destroy(c); }  // shared planes go with their last chain
-    } guard{chains};
-    int rc = BMM_OK;
-    for (int c = 0; c < n_chains && rc == BMM_OK; ++c) {
-        rc = bmm_chain_create(&chains[(size_t)c], sampler, N, P, K, alpha, beta, gamma, a, b, batch,
-                              seed + (uint64_t)c, dev_of[(size_t)c]);
-        if (rc == BMM_OK) rc = run_prepare(chains[(size_t)c], nsamples, burnin);
-    }
-    if (rc) return rc;
-    // the data: uploaded and packed once, on the first chain's device; the bit planes (not the int32
-    // matrix: 160 MB instead of 4 GB at K=20, N=1e7, P=100) broadcast once to the other devices
-    std::vector<bmm_chain*> holder(devs.size(), nullptr);  // first chain of each device: owns its planes
-    for (size_t q = 0; q < devs.size(); ++q)
-        for (int c = 0; c < n_chains && !holder[q]; ++c)
-            if (dev_of[(size_t)c] == devs[q]) holder[q] = chains[(size_t)c];
-    rc = bmm_chain_set_data_host(holder[0], X);
-    if (rc) return rc;
-    if (devs.size() > 1) {
-        if (!holder[0]->bits) return set_err(BMM_E_UNSUPPORTED, "a run over several devices broadcasts bit planes");
-        std::vector<void*> bufs(devs.size(), nullptr);
-        int64_t words = 0;
-        for (size_t q = 0; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes(holder[q], &bufs[q], &words);
-        if (rc == BMM_OK) rc = rccl_broadcast_words(devs, bufs, (size_t)words);
-        for (size_t q = 1; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes_filled(holder[q]);
-        if (rc) return rc;
-    }
-    for (int c = 0; c < n_chains; ++c) {
-        bmm_chain* ch = chains[(size_t)c];
-        if (ch->have_data) continue;
+        // the data: uploaded and packed once, on the first chain's device; the bit planes (not the int32
+        // matrix: 160 MB instead of 4 GB at K=20, N=1e7, P=100) broadcast once to the other devices
+        std::vector<bmm_chain*> holder(devs.size(), nullptr);  // first chain of each device: owns its planes
         for (size_t q = 0; q < devs.size(); ++q)
-            if (devs[q] == dev_of[(size_t)c]) rc = bmm_chain_share_data(ch, holder[q]);
+            for (int c = 0; c < n_chains && !holder[q]; ++c)
+                if (dev_of[(size_t)c] == devs[q]) holder[q] = chains[(size_t)c];
+        rc = bmm_chain_set_data_host(holder[0], X);
         if (rc) return rc;
-    }
-    // one host thread per chain; each enqueues on its own stream, so chains on one device overlap
-    std::vector<int> status((size_t)n_chains, BMM_OK);
-    std::vector<std::string> msg((size_t)n_chains);
-    std::vector<std::thread> th;
-    for (int c = 0; c < n_chains; ++c)
-        th.emplace_back([&, c]() {
-            status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
-            if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
-        });
-    for (std::thread& t : th) t.join();
-    for (int c = 0; c < n_chains; ++c)
-        if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
-    return BMM_OK;
+        if (devs.size() > 1) {
+            if (!holder[0]->bits) return set_err(BMM_E_UNSUPPORTED, "a run over several devices broadcasts bit planes");
+            std::vector<void*> bufs(devs.size(), nullptr);
+            int64_t words = 0;
+            for (size_t q = 0; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes(holder[q], &bufs[q], &words);
+            if (rc == BMM_OK) rc = rccl_broadcast_words(devs, bufs, (size_t)words);
+            for (size_t q = 1; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes_filled(holder[q]);
+            if (rc) return rc;
+        }
+        for (int c = 0; c < n_chains; ++c) {
+            bmm_chain* ch = chains[(size_t)c];
+            if (ch->have_data) continue;
+            for (size_t q = 0; q < devs.size(); ++q)
+                if (devs[q] == dev_of[(size_t)c]) rc = bmm_chain_share_data(ch, holder[q]);
+            if (rc) return rc;
+        }
+        // one host thread per chain; each enqueues on its own stream, so chains on one device overlap
+        std::vector<int> status((size_t)n_chains, BMM_OK);
+        std::vector<std::string> msg((size_t)n_chains);
+        std::vector<std::thread> th;
+        for (int c = 0; c < n_chains; ++c)
+            th.emplace_back([&, c]() {
+                status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
+                if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+            });
+        for (std::thread& t : th) t.join();
+        for (int c = 0; c < n_chains; ++c)
+            if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
+        return BMM_OK;
+    });
 }
 
 // n resident chains advanced by `sweeps` sweeps each, one host thread per chain (launches of chains
 // that share a device overlap on their streams).  Returns without waiting for the GPU, as bmm_chain_sweeps.
 int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int sweeps) {
-    if (!chains || n_chains < 1) return set_err(BMM_E_ARG, "no chains");
-    if (n_chains == 1) return bmm_chain_sweeps(chains[0], sweeps);
-    std::vector<int> status((size_t)n_chains, BMM_OK);
-    std::vector<std::string> msg((size_t)n_chains);
-    std::vector<std::thread> th;
-    for (int c = 0; c < n_chains; ++c)
-        th.emplace_back([&, c]() {
-            status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
-            if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
-        });
-    for (std::thread& t : th) t.join();
-    for (int c = 0; c < n_chains; ++c)
-        if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
-    return BMM_OK;
+    return guarded([&]() -> int {
+        if (!chains || n_chains < 1) return set_err(BMM_E_ARG, "no chains");
+        if (n_chains == 1) return bmm_chain_sweeps(chains[0], sweeps);
+        std::vector<int> status((size_t)n_chains, BMM_OK);
+        std::vector<std::string> msg((size_t)n_chains);
+        std::vector<std::thread> th;
+        for (int c = 0; c < n_chains; ++c)
+            th.emplace_back([&, c]() {
+                status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
+                if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+            });
+        for (std::thread& t : th) t.join();
+        for (int c = 0; c < n_chains; ++c)
+            if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
+        return BMM_OK;
+    });
 }
 
 // The broadcast of bmm_multi_run on a pattern: fills `words` 32-bit words on devices[0], broadcasts them
 // to every listed device through RCCL (also with a single device: the library is opened, a
 // communicator built and the collective run) and compares.  What a box without several GPUs can check.
 int bmm_multi_selfcheck(int n_devices, const int* devices, int64_t words) {
-    if (n_devices < 1 || !devices || words < 1) return set_err(BMM_E_ARG, "bad argument");
-    std::vector<int> devs(devices, devices + n_devices);
-    for (int q = 0; q < n_devices; ++q)
-        for (int r2 = 0; r2 < q; ++r2)
-            if (devs[(size_t)q] == devs[(size_t)r2]) return set_err(BMM_E_ARG, "devices must be distinct");
-    std::vector<uint32_t> pat((size_t)words), got((size_t)words);
-    for (int64_t i = 0; i < words; ++i) pat[(size_t)i] = (uint32_t)i * 2654435761u + 12345u;
-    std::vector<DevBuf> bufs((size_t)n_devices);
-    std::vector<void*> ptrs((size_t)n_devices);
-    for (int q = 0; q < n_devices; ++q) {
-        HIP_TRY(hipSetDevice(devs[(size_t)q]));
-        HIP_TRY(bufs[(size_t)q].alloc((size_t)words * 4));
-        ptrs[(size_t)q] = bufs[(size_t)q].p;
-        if (q == 0) HIP_TRY(hipMemcpy(ptrs[0], pat.data(), (size_t)words * 4, hipMemcpyHostToDevice));
-        else HIP_TRY(hipMemset(ptrs[(size_t)q], 0, (size_t)words * 4));
-    }
-    if (n_devices == 1) {  // rccl_broadcast_words skips a single device; here the collective itself is the point
-        Rccl r;
-        int rc = rccl_open(r);
-        if (rc) return rc;
-        ncclComm_t comm = nullptr;
-        ncclResult_t e = r.CommInitAll(&comm, 1, devs.data());
-        if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclCommInitAll failed: %s", r.GetErrorString(e));
-        hipStream_t st = nullptr;
-        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (he == hipSuccess) {
-            e = r.Broadcast(ptrs[0], ptrs[0], (size_t)words, ncclUint32, 0, comm, st);
-            he = hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
+    return guarded([&]() -> int {
+        if (n_devices < 1 || !devices || words < 1) return set_err(BMM_E_ARG, "bad argument");
+        std::vector<int> devs(devices, devices + n_devices);
+        for (int q = 0; q < n_devices; ++q)
+            for (int r2 = 0; r2 < q; ++r2)
+                if (devs[(size_t)q] == devs[(size_t)r2]) return set_err(BMM_E_ARG, "devices must be distinct");
+        std::vector<uint32_t> pat((size_t)words), got((size_t)words);
+        for (int64_t i = 0; i < words; ++i) pat[(size_t)i] = (uint32_t)i * 2654435761u + 12345u;
+        std::vector<DevBuf> bufs((size_t)n_devices);
+        std::vector<void*> ptrs((size_t)n_devices);
+        for (int q = 0; q < n_devices; ++q) {
+            HIP_TRY(hipSetDevice(devs[(size_t)q]));
+            HIP_TRY(bufs[(size_t)q].alloc((size_t)words * 4));
+            ptrs[(size_t)q] = bufs[(size_t)q].p;
+            if (q == 0) HIP_TRY(hipMemcpy(ptrs[0], pat.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+            else HIP_TRY(hipMemset(ptrs[(size_t)q], 0, (size_t)words * 4));
         }
-        (void)r.CommDestroy(comm);
-        if (he != hipSuccess) return set_err(BMM_E_HIP, "self-check stream failed: %s", hipGetErrorString(he));
-        if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclBroadcast failed: %s", r.GetErrorString(e));
-    } else {
-        int rc = rccl_broadcast_words(devs, ptrs, (size_t)words);
-        if (rc) return rc;
-    }
-    for (int q = 0; q < n_devices; ++q) {
-        HIP_TRY(hipSetDevice(devs[(size_t)q]));
-        HIP_TRY(hipMemcpy(got.data(), ptrs[(size_t)q], (size_t)words * 4, hipMemcpyDeviceToHost));
-        if (std::memcmp(got.data(), pat.data(), (size_t)words * 4) != 0)
-            return set_err(BMM_E_RCCL, "device %d holds different words after the broadcast", devs[(size_t)q]);
-    }
-    return BMM_OK;
+        if (n_devices == 1) {  // rccl_broadcast_words skips a single device; here the collective itself is the point
+            Rccl r;
+            int rc = rccl_open(r);
+            if (rc) return rc;
+            ncclComm_t comm = nullptr;
+            ncclResult_t e = r.CommInitAll(&comm, 1, devs.data());
+            if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclCommInitAll failed: %s", r.GetErrorString(e));
+            hipStream_t st = nullptr;
+            hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (he == hipSuccess) {
+                e = r.Broadcast(ptrs[0], ptrs[0], (size_t)words, ncclUint32, 0, comm, st);
+                he = hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
+            (void)r.CommDestroy(comm);
+            if (he != hipSuccess) return set_err(BMM_E_HIP, "self-check stream failed: %s", hipGetErrorString(he));
+            if (e != ncclSuccess) return set_err(BMM_E_RCCL, "ncclBroadcast failed: %s", r.GetErrorString(e));
+        } else {
+            int rc = rccl_broadcast_words(devs, ptrs, (size_t)words);
+            if (rc) return rc;
+        }
+        for (int q = 0; q < n_devices; ++q) {
+            HIP_TRY(hipSetDevice(devs[(size_t)q]));
+            HIP_TRY(hipMemcpy(got.data(), ptrs[(size_t)q], (size_t)words * 4, hipMemcpyDeviceToHost));
+            if (std::memcmp(got.data(), pat.data(), (size_t)words * 4) != 0)
+                return set_err(BMM_E_RCCL, "device %d holds different words after the broadcast", devs[(size_t)q]);
+        }
+        return BMM_OK;
+    });
 }
 
 int bmm_device_math(int device, int op, const double* in, const double* in2, double* out, int64_t n) {
