@@ -97,6 +97,23 @@ def test_relabel_path_batched_dp_and_stickbreaking(oracle):
     assert sorted(st.samples) == [3, 4, 5, 6]
 
 
+@pytest.mark.parametrize("N,P,K,batch", [(1500, 30, 40, 1500),     # more than 32 categories: the 512-thread emitting twin
+                                         (1200, 128, 24, 1200)])   # own-cluster tables beyond LDS (second tier)
+def test_probability_hand_off_on_the_wide_and_second_tier_kernels(oracle, N, P, K, batch):
+    X, _, _, _ = synth(N, P, 4, K)
+    z0 = _z0(N, K, 2)
+    st = RecordingStephens(K)
+    ns, burnin = 5, 2
+    got = bm.gibbs_collapsed(X, ns, K, alpha=0.7, burnin=burnin, relabel=True, burnrelabel=1, seed=19, batch=batch,
+                             initial_K=z0, stephens=st)
+    want = oracle.collapsed(X, z0, ns, K, 0.7, 0.5, 0.5, 1, 1, 0, seed=19, batch=batch)
+    assert np.array_equal(got["z_original"], want["z"][burnin:])
+    for j, m in [(1, st.cube[:, :, 0])] + [(j, st.samples[j]) for j in (2, 4)]:
+        for i in (0, N // 3, N - 1):
+            _, norm = oracle.collapsed_cond(X, want["z"][j - 1], i, K, 0.7, 0.5, 0.5, spec=True)
+            assert np.array_equal(m[i], norm), (j, i)
+
+
 def test_a_failing_hook_stops_the_run_cleanly():
     X, _, _, _ = synth(500, 8, 2, 1)
 
