@@ -92,6 +92,9 @@ const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
 constexpr int kThreadsSmall = 1024;  // KT <= 12: 128 VGPRs
 constexpr int kThreadsMid = 768;     // KT 16, 20: 168 VGPRs
 constexpr int kThreadsLarge = 512;   // 256 VGPRs
+#ifndef BMM_STREAM_MODE
+#define BMM_STREAM_MODE 2  // chains that share a device: a hardware queue of its own each (chain_stream_create)
+#endif
 #ifndef BMM_STAGE_WIDE
 #define BMM_STAGE_WIDE 32
 #endif
@@ -235,6 +238,7 @@ struct bmm_chain {
     ChainParams p{};
     int device = 0;
     hipStream_t stream = nullptr;
+    bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
@@ -341,10 +345,63 @@ int32_t* label_row(bmm_chain* c, int j) {
     return c->dZ[j & 1];
 }
 
+// A chain's stream.  The runtime pools at most four hardware queues per priority level and lets later
+// streams share them -- with whatever the host framework created before -- and two chains on one queue
+// serialise: four chains of the north-star shape on one GPU ran at 10.5 k sweeps/s in all on plain
+// streams in a fresh process and at 5.5 k (no overlap at all) at the end of bench.py's sequence of
+// workloads; streams on the high-priority level, and GPU_MAX_HW_QUEUES=8, fixed the first case and not
+// the second (profiles/r02/README.md).  A stream created with a CU mask -- here the full one -- gets a
+// hardware queue of its own from the runtime, whatever came before: 14.9-15.7 k in both cases.  It costs
+// about 6 ms more per chain created, and beyond four chains per device the queues start to thrash (8
+// chains: 9.9 k against 12.5 k on shared queues).  mode 0: plain stream; 1: high priority; 2: CU mask.
+int chain_stream_create(bmm_chain* c, bool dedicated) {
+    int mode = dedicated ? BMM_STREAM_MODE : 0;
+    if (const char* m = dbg_env("BMM_DEBUG_STREAM")) mode = atoi(m);
+    hipError_t e = hipErrorUnknown;
+    hipStream_t st = nullptr;
+    if (mode == 1) {
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest);
+    } else if (mode == 2) {
+        uint32_t mask[16];
+        for (uint32_t& w : mask) w = 0xffffffffu;
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, c->device);
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    }
+    c->stream = st;
+    c->dedicated_queue = dedicated;
+    return BMM_OK;
+}
+
+// A chain that starts sharing its device with another one moves to a stream with a hardware queue of its
+// own (a lone chain keeps a plain stream: the dedicated queue costs about 6 ms to create).  Only before
+// the first sweep: nothing but the finished data hand-over has run on the old stream.
+int chain_dedicated_queue(bmm_chain* c) {
+    if (c->dedicated_queue || c->started) return BMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t old = c->stream;
+    if (old) HIP_TRY(hipStreamSynchronize(old));
+    int rc = chain_stream_create(c, true);
+    if (rc) { c->stream = old; return rc; }
+    if (old) (void)hipStreamDestroy(old);
+    return BMM_OK;
+}
+
 int chain_alloc(bmm_chain* c) {
     const ChainParams& p = c->p;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // (chains that come to share a device are moved to streams with hardware queues of their own:
+    // chain_dedicated_queue)
+    {
+        int rcs = chain_stream_create(c, false);
+        if (rcs) return rcs;
+    }
     const size_t nz = (size_t)p.N * sizeof(int32_t);
     HIP_TRY(hipMalloc(&c->dZ[0], nz));
     HIP_TRY(hipMalloc(&c->dZ[1], nz));
@@ -817,13 +874,16 @@ int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
 }
 
 // ---- bit planes shared between chains, or filled by the caller (a broadcast) ----------------
-int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from) {
+int bmm_chain_share_data(bmm_chain* c, bmm_chain* from) {
     if (!c || !from) return set_err(BMM_E_ARG, "null argument");
     if (c->started || c->have_data) return set_err(BMM_E_STATE, "the chain already has its data");
     if (!from->have_data || !from->bits || !from->dXb) return set_err(BMM_E_STATE, "the source chain holds no bit planes");
     if (from->device != c->device) return set_err(BMM_E_ARG, "chains on different devices cannot share planes");
     if (from->p.N != c->p.N || from->p.P != c->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
     if (!c->bits) return set_err(BMM_E_STATE, "the int32 layout streams the caller's matrix: hand it over instead");
+    int rcq = chain_dedicated_queue(from);  // two chains on one device: a hardware queue each
+    if (rcq == BMM_OK) rcq = chain_dedicated_queue(c);
+    if (rcq) return rcq;
     c->planes = from->planes;
     c->planes->refs.fetch_add(1);
     c->dXb = from->dXb;

@@ -153,7 +153,8 @@ int bmm_full_run_probs(const int32_t* X, int64_t N, int P, const double* initial
 /* ---- several independent chains in one call (SURVEY.md section 8 rows b and e) ---------------
  * n_chains chains of one sampler over the same data, chain c keyed seed + c and resident on
  * devices[c] (all on device 0 when devices is NULL; a device may appear several times: its chains
- * share one copy of the data and overlap on their own streams).  X is uploaded and packed into bit
+ * share one copy of the data and overlap on streams with hardware queues of their own -- about four
+ * chains per device is where that pays).  X is uploaded and packed into bit
  * planes once, on devices[0]; when the run spans several devices the planes -- 4 * ceil(P/32) bytes
  * per observation, not the int32 matrix -- are broadcast once with RCCL over xGMI inside this
  * process (ncclCommInitAll over the distinct devices, one ncclBroadcast; librccl is opened on
@@ -201,9 +202,11 @@ int bmm_chain_get_x_layout(const bmm_chain* c, int* layout);
 int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X);
 int bmm_chain_set_data_device(bmm_chain* c, const void* dX);
 /* Several chains on one device over the same data: `c` shares the bit planes `from` holds (same
- * device, N and P).  The planes are reference-counted: chains may be destroyed in any order, the last
- * one frees them.  What bmm_multi_run does for chains that share a device. */
-int bmm_chain_share_data(bmm_chain* c, const bmm_chain* from);
+ * device, N and P), before either has run a sweep.  The planes are reference-counted: chains may be
+ * destroyed in any order, the last one frees them.  Both chains move to streams with hardware queues of
+ * their own, so that their launches overlap (up to about four chains per device pay off).  What
+ * bmm_multi_run does for chains that share a device. */
+int bmm_chain_share_data(bmm_chain* c, bmm_chain* from);
 /* The chain's bit planes on its device: ceil(P/32) planes of N 32-bit words (allocated on first
  * call).  A rank that received them from a broadcast (160 MB instead of the 4 GB int32 matrix at
  * K=20, N=1e7, P=100) declares them complete with bmm_chain_planes_filled, which waits for the device. */
