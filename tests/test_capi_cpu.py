@@ -55,6 +55,27 @@ def test_argument_validation_needs_no_gpu():
         bm.gibbs_dp(X, 10, burnin=10)
 
 
+def test_new_entry_points_validate_before_touching_a_device():
+    import ctypes as C
+    L = _capi.lib()
+    tab = (C.c_void_p * 1)(None)
+    rc = L.bmm_multi_run(C.c_int(0), C.c_int(0), None, None, C.c_int64(10), C.c_int(3), None, None, None, C.c_int(5),
+                         C.c_int(2), C.c_double(1.0), C.c_double(0.5), C.c_double(0.5), C.c_double(1), C.c_double(1),
+                         C.c_int(1), C.c_int64(0), C.c_uint64(1), None, tab, tab, tab)
+    assert rc == 1 and b"n_chains" in L.bmm_last_error()
+    rc = L.bmm_multi_run(C.c_int(9), C.c_int(1), None, None, C.c_int64(10), C.c_int(3), None, None, None, C.c_int(5),
+                         C.c_int(2), C.c_double(1.0), C.c_double(0.5), C.c_double(0.5), C.c_double(1), C.c_double(1),
+                         C.c_int(1), C.c_int64(0), C.c_uint64(1), None, tab, tab, tab)
+    assert rc == 1 and b"sampler" in L.bmm_last_error()
+    assert L.bmm_multi_selfcheck(C.c_int(0), None, C.c_int64(16)) == 1
+    assert L.bmm_chains_sweeps(None, C.c_int(0), C.c_int(1)) == 1
+    assert L.bmm_chain_share_data(None, None) == 1 and L.bmm_chain_planes(None, None, None) == 1
+    # the stated tolerance is one number in the header and in the Python mirror
+    hdr = open(os.path.join(ROOT, "include", "bmm_mcmc.h")).read()
+    assert "#define BMM_TOL_PROPORTIONS %g" % bm.TOL_PROPORTIONS in hdr
+    assert "#define BMM_TOL_THETA %g" % bm.TOL_THETA in hdr
+
+
 @pytest.mark.skipif(_capi.device_count() > 0, reason="a GPU is present")
 def test_no_cpu_fallback_without_a_device():
     X = np.zeros((10, 3), dtype=np.int32)

@@ -62,6 +62,29 @@ def test_shim_is_valid_c_against_the_r_api_declarations(defs):
     assert r.returncode == 0, r.stderr
 
 
+def test_shim_object_defines_every_registered_symbol(tmp_path):
+    """Compiled to an object (against the same declarations), the shim defines R_init_bmmmcmc and every entry
+    it registers; with -DBMM_SHIM_FORWARD the three untouched entry points become undefined references that
+    the package's own objects resolve."""
+    gcc, nm = shutil.which("gcc"), shutil.which("nm")
+    assert gcc and nm
+    base = [gcc, "-c", "-std=gnu11", "-fPIC", "-Wno-cast-function-type", "-I" + os.path.join(ROOT, "tests", "r_api_stub"),
+            "-I" + os.path.join(ROOT, "include")]
+    untouched = {"_bmmmcmc_rdirichlet_cpp", "_bmmmcmc_my_lpsolve", "_bmmmcmc_my_stephens_batch"}
+    for defs, undefined in (([], set()), (["-DBMM_SHIM_FORWARD"], untouched)):
+        obj = str(tmp_path / ("shim%d.o" % len(defs)))
+        subprocess.run(base + defs + ["-o", obj, SHIM], check=True, capture_output=True)
+        out = subprocess.run([nm, obj], capture_output=True, text=True, check=True).stdout
+        defined = {l.split()[-1] for l in out.splitlines() if " T " in l}
+        undef = {l.split()[-1] for l in out.splitlines() if l.strip().startswith("U ")}
+        names = set(_table(SHIM))
+        assert "R_init_bmmmcmc" in defined
+        assert names - undefined <= defined, names - undefined - defined
+        assert undefined <= undef
+        for sym in ("bmm_collapsed_run", "bmm_dp_run", "bmm_sb_run", "bmm_full_run", "bmm_multi_run", "bmm_last_error"):
+            assert sym in undef          # resolved by libbmmmcmc_hip.so, which exports them (test_capi_cpu)
+
+
 def test_registration_table_matches_the_reference():
     got = _table(SHIM)
     for name, arity in REFERENCE_TABLE.items():
