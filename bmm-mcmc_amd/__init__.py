@@ -16,9 +16,10 @@ import numpy as _np
 
 from . import _capi
 from ._capi import BmmError, NA_INTEGER
+from .rdata import read_rdata_matrix  # the package's bundled data sets (data/*.RData) without R
 
 __all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
-           "default_batch", "sweep_chains", "TOL_PROPORTIONS", "TOL_THETA"]
+           "default_batch", "sweep_chains", "read_rdata_matrix", "TOL_PROPORTIONS", "TOL_THETA"]
 
 # include/bmm_mcmc.h: the stated tolerance of a batch > 1 against the reference's sequential scan
 TOL_PROPORTIONS = 0.015

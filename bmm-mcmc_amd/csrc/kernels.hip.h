@@ -532,7 +532,7 @@ __device__ __forceinline__ void count_movers(bool moves, int zfrom, int zto, uin
         if (zfrom >= 0) atomicAdd(&hist[K * P + zfrom], -1);
     }
     const int thr = P >= 16 ? P >> 3 : 2;
-    if (__popcll(movers) > thr) {  // uniform
+    if ((int)__popcll(movers) > thr) {  // uniform
         if (moves) {
             int32_t* const hn = hist + zto * P;
             int32_t* const ho = hist + (zfrom < 0 ? 0 : zfrom) * P;
