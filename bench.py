@@ -123,9 +123,10 @@ def main():
     from bmm_mcmc_amd import multi, synth
 
     world, rank, local = multi.world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world == 1 and args.gpus > 1:
+        # not under torch.distributed.run: the native launcher -- one process, one chain and one host
+        # thread per GPU, the bit planes broadcast with RCCL inside the library (bmm_chains_broadcast_planes)
+        return bench_native(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # BMM_BENCH_REHEARSE=1: every rank on device 0 over gloo -- how the N > 1 code path (plane broadcast,
@@ -458,6 +459,54 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     return result
+
+
+def bench_native(args):
+    """`python bench.py --gpus N` without torch.distributed.run: the same measurement from one process.
+    One resident chain per GPU (seeds 1000 + c), the data generated and packed on GPU 0, its bit planes
+    broadcast once over RCCL by the library itself, the sweeps of all chains enqueued by one host thread
+    per chain (bmm_chains_sweeps); value = sweeps of all chains / wall time of the timed region."""
+    import numpy as np
+    import torch
+    import bmm_mcmc_amd as bm
+    from bmm_mcmc_amd import synth
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit("%d GPUs asked for, %d visible" % (n, torch.cuda.device_count()))
+    sampler, K, K_true, N, P, dseed = synth.WORKLOADS[args.workload]
+    if args.rows:
+        N = args.rows
+    chains = [bm.Chain(sampler, N, P, K, batch=args.batch if args.batch > 0 else None, seed=1000 + c, device=c)
+              for c in range(n)]
+    X, _ = synth.device_matrix(N, P, K_true, dseed, torch.device("cuda", 0))
+    chains[0].set_data_device(X.data_ptr())
+    del X
+    bm.broadcast_planes(chains)
+    for c, ch in enumerate(chains):
+        rng = np.random.default_rng(1000 + c)
+        if sampler == "collapsed":
+            ch.set_initial_labels(rng.integers(1, K + 1, N).astype(np.int32))
+        elif sampler in ("stickbreaking", "full"):
+            pi0 = np.exp(rng.random(K))
+            ch.set_initial_params(pi0 / pi0.sum(), rng.random((K, P)))
+    bm.sweep_chains(chains, args.burn + args.warmup)
+    for ch in chains:
+        ch.sync()
+    t0 = time.perf_counter()
+    bm.sweep_chains(chains, args.steps)
+    for ch in chains:
+        ch.sync()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "gibbs_sweeps_per_s", "value": n * args.steps / dt, "unit": "sweeps/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
+                   "sampler": sampler, "K": K, "N": N, "P": P, "batch": chains[0].batch, "chains": n,
+                   "launcher": "native: one process, one host thread per GPU, RCCL broadcast of the bit planes "
+                               "inside the library (bmm_chains_broadcast_planes)"}}))
+    for ch in chains:
+        ch.close()
 
 
 def bench_sharded(args, world, rank, local, dev, barrier):

@@ -19,7 +19,7 @@ from ._capi import BmmError, NA_INTEGER
 from .rdata import read_rdata_matrix  # the package's bundled data sets (data/*.RData) without R
 
 __all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
-           "default_batch", "sweep_chains", "read_rdata_matrix", "TOL_PROPORTIONS", "TOL_THETA"]
+           "default_batch", "sweep_chains", "broadcast_planes", "read_rdata_matrix", "TOL_PROPORTIONS", "TOL_THETA"]
 
 # include/bmm_mcmc.h: the stated tolerance of a batch > 1 against the reference's sequential scan
 TOL_PROPORTIONS = 0.015
@@ -485,3 +485,10 @@ def sweep_chains(chains, n):
     one device overlap on their streams.  Returns without waiting; sync each chain afterwards."""
     tab = (_C.c_void_p * len(chains))(*[c._h.value for c in chains])
     _capi.check(_capi.lib().bmm_chains_sweeps(tab, _C.c_int(len(chains)), _C.c_int(int(n))))
+
+
+def broadcast_planes(chains):
+    """Resident chains on different devices of this process, one per device: chains[0] holds the data, the
+    others receive its bit planes with one RCCL broadcast (bmm_chains_broadcast_planes)."""
+    tab = (_C.c_void_p * len(chains))(*[c._h.value for c in chains])
+    _capi.check(_capi.lib().bmm_chains_broadcast_planes(tab, _C.c_int(len(chains))))

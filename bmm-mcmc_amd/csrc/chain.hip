@@ -1558,6 +1558,33 @@ int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int sweeps) {
     });
 }
 
+// The data of resident chains on different devices from the first one's: chains[0] holds the bit planes
+// (its data are set); every other chain -- one per further device -- receives them over RCCL, as in
+// bmm_multi_run.  What a single-process multi-GPU driver of the resident API (bench.py without
+// torch.distributed.run) calls once before the sweeps.
+int bmm_chains_broadcast_planes(bmm_chain* const* chains, int n_chains) {
+    return guarded([&]() -> int {
+        if (!chains || n_chains < 1 || !chains[0]) return set_err(BMM_E_ARG, "no chains");
+        if (!chains[0]->have_data || !chains[0]->bits) return set_err(BMM_E_STATE, "the first chain holds no bit planes");
+        std::vector<int> devs;
+        std::vector<void*> bufs((size_t)n_chains, nullptr);
+        int64_t words = 0;
+        for (int c = 0; c < n_chains; ++c) {
+            bmm_chain* ch = chains[c];
+            if (!ch) return set_err(BMM_E_ARG, "null chain");
+            for (int d : devs)
+                if (d == ch->device) return set_err(BMM_E_ARG, "one chain per device here; chains on one device share (bmm_chain_share_data)");
+            if (ch->p.N != chains[0]->p.N || ch->p.P != chains[0]->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
+            devs.push_back(ch->device);
+            int rc = bmm_chain_planes(ch, &bufs[(size_t)c], &words);
+            if (rc) return rc;
+        }
+        int rc = rccl_broadcast_words(devs, bufs, (size_t)words);
+        for (int c = 1; c < n_chains && rc == BMM_OK; ++c) rc = bmm_chain_planes_filled(chains[c]);
+        return rc;
+    });
+}
+
 // The broadcast of bmm_multi_run on a pattern: fills `words` 32-bit words on devices[0], broadcasts them
 // to every listed device through RCCL (also with a single device: the library is opened, a
 // communicator built and the collective run) and compares.  What a box without several GPUs can check.

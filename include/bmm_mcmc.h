@@ -212,6 +212,10 @@ int bmm_chain_share_data(bmm_chain* c, bmm_chain* from);
  * K=20, N=1e7, P=100) declares them complete with bmm_chain_planes_filled, which waits for the device. */
 int bmm_chain_planes(bmm_chain* c, void** dXb, int64_t* n_words);
 int bmm_chain_planes_filled(bmm_chain* c);
+/* Resident chains on different devices, one per device, in one process: chains[0] holds the data; the
+ * others receive its bit planes with one RCCL broadcast (ncclCommInitAll + ncclBroadcast, as
+ * bmm_multi_run does).  Then bmm_chains_sweeps drives them, one host thread each. */
+int bmm_chains_broadcast_planes(bmm_chain* const* chains, int n_chains);
 /* starting state: collapsed needs 1-based labels; stick-breaking needs pi and theta;
  * dp starts from zero clusters and needs neither */
 int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1);

@@ -59,6 +59,19 @@ def test_multi_run_argument_errors():
         bm.gibbs_dp(X, 5, seed=1, chains=2, devices=[0, 99])
 
 
+def test_native_plane_broadcast_argument_checks():
+    """bmm_chains_broadcast_planes on what one GPU allows: one chain (nothing to send), and the refusal of
+    two chains on one device (those share, they do not broadcast)."""
+    X, _, _, _ = synth(2000, 10, 2, 1)
+    with bm.Chain("collapsed", 2000, 10, 3, seed=1) as a, bm.Chain("collapsed", 2000, 10, 3, seed=2) as b:
+        with pytest.raises(bm.BmmError, match="holds no bit planes"):
+            bm.broadcast_planes([a])
+        a.set_data(X)
+        bm.broadcast_planes([a])
+        with pytest.raises(bm.BmmError, match="one chain per device"):
+            bm.broadcast_planes([a, b])
+
+
 def test_rccl_broadcast_selfcheck_on_this_device():
     dev = (C.c_int * 1)(0)
     _capi.check(_capi.lib().bmm_multi_selfcheck(C.c_int(1), dev, C.c_int64(1 << 20)))
