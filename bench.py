@@ -320,6 +320,8 @@ def main():
         for t in cand:
             probes[t] = t * Xp.shape[0] / oracle.time_sweeps(sampler, Xp, K, 1, max(1, min(cb, Xp.shape[0])), 1000, t)
         threads = max(probes, key=probes.get)
+        # BASELINE.md (ii) also asks for the one-thread rate of the port: two sweeps of the probe sample
+        one_thread = Xp.shape[0] * 2 / oracle.time_sweeps(sampler, Xp, K, 2, max(1, min(cb, Xp.shape[0])), 1000, 1)
         probe = oracle.time_sweeps(sampler, Xh, K, 1, cb, 1000, threads)  # size the leg to ~cpu-seconds
         cpu_sweeps = int(max(2, min(200, round(args.cpu_seconds / max(probe, 1e-3)))))
         secs = oracle.time_sweeps(sampler, Xh, K, cpu_sweeps, cb, 1000, threads)
@@ -329,7 +331,8 @@ def main():
                          "allocations/s / N" % (label, threads, cpu_sweeps, rows),
                "allocations_per_s": alloc_s, "seconds": secs,
                "cores_per_socket": per_socket, "cpus_available_to_this_process": avail,
-               "thread_count_probe_allocations_per_s": {str(t): v for t, v in probes.items()}}
+               "thread_count_probe_allocations_per_s": {str(t): v for t, v in probes.items()},
+               "one_thread": {"value": one_thread / N, "unit": "sweeps/s", "cores": 1, "allocations_per_s": one_thread}}
         if threads < per_socket:
             out["one_socket_extrapolated"] = {
                 "value": alloc_s / N * per_socket / threads,

@@ -875,9 +875,6 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 const int g_lo = (SB * h + kGroupW - 1) / kGroupW;
                 int g_hi = (SB * (h + 1) + kGroupW - 1) / kGroupW;
                 g_hi = g_hi < G ? g_hi : G;
-#ifdef BMM_EXP_NOLOOKUP  // timing experiment only (tools/exp_lib.sh): one lookup group per stage
-                g_hi = g_lo + 1 < g_hi ? g_lo + 1 : g_hi;
-#endif
 #pragma unroll 1
                 for (int g = g_lo; g < g_hi; ++g) {
                     const unsigned nib = __builtin_amdgcn_alignbit(nxt, cur, (unsigned)(g * kGroupW - 32 * wd)) &
@@ -920,11 +917,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double run = 0.0;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-#ifdef BMM_EXP_NODRAW  // timing experiment only: no exponentials
-                const double w = (acc[k] - m) + 2.0;
-#else
                 const double w = expw_tab(acc[k] - m, ET);
-#endif
                 if (EMIT && kb + k < p.Kc && pos.valid) a.wts[(int64_t)(kb + k) * p.N + pos.i] = w;
                 if (SPLIT == 1) { run = run + w; acc[k] = run; }
                 else acc[k] = w;
