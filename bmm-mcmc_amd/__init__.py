@@ -19,7 +19,7 @@ from ._capi import BmmError, NA_INTEGER
 from .rdata import read_rdata_matrix  # the package's bundled data sets (data/*.RData) without R
 
 __all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
-           "default_batch", "sweep_chains", "broadcast_planes", "read_rdata_matrix", "TOL_PROPORTIONS", "TOL_THETA"]
+           "default_batch", "sweep_chains", "broadcast_planes", "read_rdata_matrix", "chain_summary", "TOL_PROPORTIONS", "TOL_THETA"]
 
 # include/bmm_mcmc.h: the stated tolerance of a batch > 1 against the reference's sequential scan
 TOL_PROPORTIONS = 0.015
@@ -492,3 +492,31 @@ def broadcast_planes(chains):
     others receive its bit planes with one RCCL broadcast (bmm_chains_broadcast_planes)."""
     tab = (_C.c_void_p * len(chains))(*[c._h.value for c in chains])
     _capi.check(_capi.lib().bmm_chains_broadcast_planes(tab, _C.c_int(len(chains))))
+
+
+def chain_summary(obj, cluster_threshold=0.1):
+    """The numbers `plot_gibbs` draws from a returned chain object (R/utils.R:147-190), without the plots:
+    `proportions` S x K, the share of the observations holding each label in each kept sample (labels that
+    are NA -- the DP and explicit samplers' row 0 at burnin = 0 -- do not count); `clusters`, the 1-based
+    labels that exceed `cluster_threshold` in some sample after the first (plot_gibbs drops sample 1), in
+    order of first appearance; `theta` K x P x S restricted to those labels (others NaN), as the theta
+    panel shows it."""
+    z = _np.asarray(obj["z"])
+    th = _np.asarray(obj["theta"], dtype=_np.float64)
+    K = th.shape[0]
+    S, N = z.shape
+    props = _np.zeros((S, K))
+    for s in range(S):
+        lab = z[s]
+        lab = lab[(lab >= 1) & (lab <= K)]
+        if lab.size:
+            props[s] = _np.bincount(lab - 1, minlength=K) / lab.size
+    clusters = []
+    for s in range(1, S):
+        for k in _np.nonzero(props[s] > cluster_threshold)[0]:
+            if k + 1 not in clusters:
+                clusters.append(int(k) + 1)
+    shown = _np.full_like(th, _np.nan)
+    for k in clusters:
+        shown[k - 1] = th[k - 1]
+    return {"proportions": props, "clusters": clusters, "theta": shown}

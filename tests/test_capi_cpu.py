@@ -83,3 +83,16 @@ def test_no_cpu_fallback_without_a_device():
         bm.gibbs_collapsed(X, 10, 2, seed=1)
     with pytest.raises(bm.BmmError, match="no HIP device"):
         bm.Chain("dp", 10, 3, 5)
+
+
+def test_chain_summary_derives_what_plot_gibbs_plots():
+    """R/utils.R:147-190: per-sample label shares, labels above the threshold after sample 1"""
+    import numpy as np
+    import bmm_mcmc_amd as bm
+    z = np.array([[1, 1, 1, 1], [1, 1, 2, 2], [3, 1, 1, 1], [-2147483648, 1, 2, 2]], dtype=np.int32)
+    theta = np.arange(3 * 2 * 4, dtype=float).reshape(3, 2, 4)
+    s = bm.chain_summary({"z": z, "theta": theta}, cluster_threshold=0.3)
+    assert np.allclose(s["proportions"][1], [0.5, 0.5, 0.0])
+    assert np.allclose(s["proportions"][3], [1 / 3, 2 / 3, 0.0])
+    assert s["clusters"] == [1, 2]  # label 3 never exceeds 0.3; sample 1 (all ones) is not consulted
+    assert np.isnan(s["theta"][2]).all() and np.array_equal(s["theta"][:2], theta[:2])
