@@ -15,7 +15,7 @@ NA_INTEGER = -2147483648
 
 # every symbol include/bmm_mcmc.h declares
 SYMBOLS = [
-    "bmm_last_error", "bmm_spec_group_width", "bmm_default_batch", "bmm_collapsed_run", "bmm_dp_run",
+    "bmm_last_error", "bmm_spec_group_width", "bmm_spec_group_width_own", "bmm_spec_group_width_for", "bmm_default_batch", "bmm_collapsed_run", "bmm_dp_run",
     "bmm_sb_run", "bmm_full_run", "bmm_chain_create", "bmm_chain_destroy", "bmm_chain_set_data_host",
     "bmm_chain_set_data_device", "bmm_chain_set_x_layout", "bmm_chain_get_x_layout", "bmm_chain_set_initial_labels", "bmm_chain_set_initial_params",
     "bmm_chain_sweeps", "bmm_chain_sweeps_counts", "bmm_chain_sweep_probs", "bmm_chain_set_shard", "bmm_chain_shard_resample",

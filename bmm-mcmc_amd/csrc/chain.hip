@@ -113,22 +113,25 @@ int threads_for(int kt, bool bits) {
 
 typedef void (*resample_fn)(ChainParams, ResampleArgs);
 // BITS: X streamed as bit planes (k_pack_bits) instead of the int32 matrix as handed over
-template <int MINUS, bool BITS>
+// GW: the shape's group width (bmm_spec.h).  The default-sized kernels, their two-lane forms and their
+// emitting twins exist for both widths; the stepped-down workgroup sizes for the preferred width only
+// (shapes that fall back to the narrower groups are the ones with big tables).
+template <int MINUS, bool BITS, int GW>
 resample_fn resample_kernel_m(int kt) {
     constexpr int SW = BITS ? 16 : kStageWide;
     switch (kt) {
-        case 4: return k_resample<4, kThreadsSmall, MINUS, SW, BITS>;
-        case 8: return k_resample<8, kThreadsSmall, MINUS, SW, BITS>;
-        case 12: return k_resample<12, kThreadsSmall, MINUS, SW, BITS>;
-        case 16: return k_resample<16, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS>;
-        case 20: return k_resample<20, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS>;
-        case 24: return k_resample<24, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
-        case 28: return k_resample<28, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
-        case 32: return k_resample<32, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS>;
-        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, BITS>;
-        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, BITS>;
-        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, BITS>;
-        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, BITS>;
+        case 4: return k_resample<4, kThreadsSmall, MINUS, SW, BITS, 1, false, GW>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS, SW, BITS, 1, false, GW>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS, SW, BITS, 1, false, GW>;
+        case 16: return k_resample<16, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS, 1, false, GW>;
+        case 20: return k_resample<20, BITS ? kThreadsSmall : kThreadsMid, MINUS, SW, BITS, 1, false, GW>;
+        case 24: return k_resample<24, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 28: return k_resample<28, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 32: return k_resample<32, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
     }
     return nullptr;
 }
@@ -184,48 +187,60 @@ resample_fn resample_kernel_at(int kt, int nt, int minus, bool bits) {
 }
 // more than 32 accumulators on bit planes: two lanes per observation (SPLIT = 2 in kernels.hip.h)
 constexpr int kThreadsSplit = 1024;
-template <int MINUS>
-resample_fn resample_kernel_split(int kt) {
+template <int MINUS, int GW>
+resample_fn resample_kernel_split_w(int kt) {
     switch (kt) {
-        case 40: return k_resample<40, kThreadsSplit, MINUS, 16, true, 2>;
-        case 48: return k_resample<48, kThreadsSplit, MINUS, 16, true, 2>;
-        case 56: return k_resample<56, kThreadsSplit, MINUS, 16, true, 2>;
-        case 64: return k_resample<64, kThreadsSplit, MINUS, 16, true, 2>;
+        case 40: return k_resample<40, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
+        case 48: return k_resample<48, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
+        case 56: return k_resample<56, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
+        case 64: return k_resample<64, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
     }
     return nullptr;
+}
+template <int MINUS>
+resample_fn resample_kernel_split(int kt, int gw) {
+    return gw == kGroupW ? resample_kernel_split_w<MINUS, kGroupW>(kt) : resample_kernel_split_w<MINUS, kGroupWAlt>(kt);
 }
 // The weight-emitting twins (EMIT) of the default-sized bit-plane kernels: what a sweep runs on
 // while its allocation probabilities go to the host (any workgroup size serves any batch).
-template <int MINUS>
+template <int MINUS, int GW>
 resample_fn resample_kernel_emit_m(int kt) {
     switch (kt) {
-        case 4: return k_resample<4, kThreadsSmall, MINUS, 16, true, 1, true>;
-        case 8: return k_resample<8, kThreadsSmall, MINUS, 16, true, 1, true>;
-        case 12: return k_resample<12, kThreadsSmall, MINUS, 16, true, 1, true>;
-        case 16: return k_resample<16, kThreadsSmall, MINUS, 16, true, 1, true>;
-        case 20: return k_resample<20, kThreadsSmall, MINUS, 16, true, 1, true>;
-        case 24: return k_resample<24, kThreadsMid, MINUS, 16, true, 1, true>;
-        case 28: return k_resample<28, kThreadsMid, MINUS, 16, true, 1, true>;
-        case 32: return k_resample<32, kThreadsMid, MINUS, 16, true, 1, true>;
-        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, true, 1, true>;
-        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, true, 1, true>;
-        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, true, 1, true>;
-        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, true, 1, true>;
+        case 4: return k_resample<4, kThreadsSmall, MINUS, 16, true, 1, true, GW>;
+        case 8: return k_resample<8, kThreadsSmall, MINUS, 16, true, 1, true, GW>;
+        case 12: return k_resample<12, kThreadsSmall, MINUS, 16, true, 1, true, GW>;
+        case 16: return k_resample<16, kThreadsSmall, MINUS, 16, true, 1, true, GW>;
+        case 20: return k_resample<20, kThreadsSmall, MINUS, 16, true, 1, true, GW>;
+        case 24: return k_resample<24, kThreadsMid, MINUS, 16, true, 1, true, GW>;
+        case 28: return k_resample<28, kThreadsMid, MINUS, 16, true, 1, true, GW>;
+        case 32: return k_resample<32, kThreadsMid, MINUS, 16, true, 1, true, GW>;
+        case 40: return k_resample<40, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
+        case 48: return k_resample<48, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
+        case 56: return k_resample<56, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
+        case 64: return k_resample<64, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
     }
     return nullptr;
 }
-resample_fn resample_kernel_emit(int kt, int minus) {
-    return minus == 0 ? resample_kernel_emit_m<0>(kt)
-                      : (minus == 1 ? resample_kernel_emit_m<1>(kt) : resample_kernel_emit_m<2>(kt));
+template <int GW>
+resample_fn resample_kernel_emit_w(int kt, int minus) {
+    return minus == 0 ? resample_kernel_emit_m<0, GW>(kt)
+                      : (minus == 1 ? resample_kernel_emit_m<1, GW>(kt) : resample_kernel_emit_m<2, GW>(kt));
+}
+resample_fn resample_kernel_emit(int kt, int minus, int gw) {
+    return gw == kGroupW ? resample_kernel_emit_w<kGroupW>(kt, minus) : resample_kernel_emit_w<kGroupWAlt>(kt, minus);
 }
 
 // minus: 0 no own-cluster tables (stick-breaking), 1 in LDS, 2 in global memory
-resample_fn resample_kernel(int kt, int minus, bool bits) {
+template <int GW>
+resample_fn resample_kernel_w(int kt, int minus, bool bits) {
     if (bits)
-        return minus == 0 ? resample_kernel_m<0, true>(kt)
-                          : (minus == 1 ? resample_kernel_m<1, true>(kt) : resample_kernel_m<2, true>(kt));
-    return minus == 0 ? resample_kernel_m<0, false>(kt)
-                      : (minus == 1 ? resample_kernel_m<1, false>(kt) : resample_kernel_m<2, false>(kt));
+        return minus == 0 ? resample_kernel_m<0, true, GW>(kt)
+                          : (minus == 1 ? resample_kernel_m<1, true, GW>(kt) : resample_kernel_m<2, true, GW>(kt));
+    return minus == 0 ? resample_kernel_m<0, false, GW>(kt)
+                      : (minus == 1 ? resample_kernel_m<1, false, GW>(kt) : resample_kernel_m<2, false, GW>(kt));
+}
+resample_fn resample_kernel(int kt, int minus, bool bits, int gw) {
+    return gw == kGroupW ? resample_kernel_w<kGroupW>(kt, minus, bits) : resample_kernel_w<kGroupWAlt>(kt, minus, bits);
 }
 resample_fn resample_kernel_small_of(int kt, int minus, bool bits) {
     if (bits) return minus == 0 ? resample_kernel_small<0, true>(kt) : resample_kernel_small<1, true>(kt);
@@ -336,8 +351,23 @@ int64_t default_batch(int sampler, int64_t N) {
     return b < 1 ? 1 : b;
 }
 
-TableLayout layout_of(const bmm_chain* c) {
-    return TableLayout{c->p.G, c->p.KT, !explicit_params(c->p.mode) ? 1 : 0};
+TableLayout layout_of(const bmm_chain* c) { return layout_of(c->p, !explicit_params(c->p.mode)); }
+
+constexpr size_t kLdsMax = 163840;  // gfx950: 160 KiB per workgroup
+size_t hist_bytes_of(int K, int P) { return ((size_t)K * P + K + 4) * sizeof(int32_t); }  // histogram + chunk counter
+
+// The spec's rule for the group width of a shape (bmm_spec.h; the oracle restates it): groups of kGroupW
+// features when the whole table image of the shape and the histogram fit in LDS that way, kGroupWAlt
+// otherwise.  A pure function of (sampler, K, P).
+int group_width_rule(int sampler, int K, int P) {
+    const int cats = sampler == BMM_SAMPLER_DP ? K + 1 : K;
+    const int kt = pick_kt(cats);
+    if (kt < 0 || P > kMaxP) return kGroupWAlt;
+    ChainParams q{};
+    q.mode = sampler; q.P = P; q.K = K; q.KT = kt; q.W = kGroupW;
+    q.G = (P + kGroupW - 1) / kGroupW; q.Gm = (P + kGroupWm - 1) / kGroupWm;
+    const size_t bytes = (size_t)layout_of(q, !explicit_params(sampler)).doubles() * sizeof(double) + hist_bytes_of(K, P);
+    return bytes <= kLdsMax ? kGroupW : kGroupWAlt;
 }
 
 int32_t* label_row(bmm_chain* c, int j) {
@@ -558,20 +588,21 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
 // The resident kernel for this chain's shape, workgroup size and X layout (c->bits).
 int pick_kernel(bmm_chain* c) {
     const ChainParams& p = c->p;
-    const size_t lds_max = 163840;
+    const size_t lds_max = kLdsMax;
     const int minus = explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
     c->NT = threads_for(p.KT, c->bits);
-    c->fn = resample_kernel(p.KT, minus, c->bits);
+    const bool alt = p.W != kGroupW;  // the narrower groups: default-sized kernels only
+    c->fn = resample_kernel(p.KT, minus, c->bits, p.W);
     int split = 1;
     if (c->bits && p.KT > 32 && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
-        c->fn = minus ? resample_kernel_split<1>(p.KT) : resample_kernel_split<0>(p.KT);
+        c->fn = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W);
         c->NT = kThreadsSplit;
         split = 2;
     }
-    if (const char* dbg = dbg_env("BMM_DEBUG_THREADS")) {
+    if (const char* dbg = alt ? nullptr : dbg_env("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
         if (resample_fn f = resample_kernel_at(p.KT, nt, minus, c->bits)) { c->fn = f; c->NT = nt; }
-    } else if (c->bits && split == 1) {
+    } else if (c->bits && split == 1 && !alt) {
         // a batch that cannot give every CU a workgroup of the default size gets smaller ones
         for (int nt : {768, 512}) {
             if ((c->batch + c->NT - 1) / c->NT >= c->num_cus || nt >= c->NT) continue;
@@ -581,7 +612,7 @@ int pick_kernel(bmm_chain* c) {
     hipError_t e = hipSetDevice(c->device);
     c->fn_emit = nullptr;
     if (e == hipSuccess && c->bits) {
-        c->fn_emit = resample_kernel_emit(p.KT, minus);
+        c->fn_emit = resample_kernel_emit(p.KT, minus, p.W);
         c->NT_emit = threads_for(p.KT, true);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
         int pe = 0;
@@ -601,7 +632,7 @@ int pick_kernel(bmm_chain* c) {
     // tables are small enough for several of them per CU (otherwise fewer waves per CU just hurts)
     c->OT = c->NT / split;
     const int64_t tiles = (c->batch + c->NT - 1) / c->NT;
-    if (split == 1 && tiles < c->num_cus && c->NT > 256 && (c->lds_bytes * 4 <= lds_max || dbg_env("BMM_DEBUG_SMALL")) &&
+    if (split == 1 && !alt && tiles < c->num_cus && c->NT > 256 && (c->lds_bytes * 4 <= lds_max || dbg_env("BMM_DEBUG_SMALL")) &&
         minus != 2 && !dbg_env("BMM_DEBUG_THREADS")) {
         resample_fn f = resample_kernel_small_of(p.KT, minus, c->bits);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -658,6 +689,11 @@ extern "C" {
 
 const char* bmm_last_error(void) { return g_err; }
 int bmm_spec_group_width(void) { return kGroupW; }
+int bmm_spec_group_width_own(void) { return kGroupWm; }
+int bmm_spec_group_width_for(int sampler, int K, int P) {
+    if (sampler < 0 || sampler > 3 || K < 1 || P < 1) return -1;
+    return group_width_rule(sampler, K, P);
+}
 int64_t bmm_default_batch(int sampler, int64_t N) { return default_batch(sampler, N); }
 
 int bmm_device_count(int* n) {
@@ -687,7 +723,10 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     bmm_chain* c = new (std::nothrow) bmm_chain();
     if (!c) return set_err(BMM_E_ARG, "out of host memory");
     ChainParams& p = c->p;
-    p.mode = sampler; p.N = N; p.Ntot = N; p.obs0 = 0; p.P = P; p.G = (P + kGroupW - 1) / kGroupW; p.K = K;
+    p.mode = sampler; p.N = N; p.Ntot = N; p.obs0 = 0; p.P = P; p.K = K;
+    p.W = group_width_rule(sampler, K, P);
+    p.G = (P + p.W - 1) / p.W;
+    p.Gm = (P + kGroupWm - 1) / kGroupWm;
     p.Kc = sampler == BMM_SAMPLER_DP ? K + 1 : K;
     p.KT = pick_kt(p.Kc);
     p.beta = beta; p.gamma = gamma; p.a = a; p.b = b; p.seed = seed;
@@ -702,8 +741,8 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
-    const size_t lds_max = 163840;  // gfx950: 160 KiB per workgroup
-    const size_t hist_bytes = ((size_t)K * P + K + 4) * sizeof(int32_t);  // histogram + the chunk counter
+    const size_t lds_max = kLdsMax;
+    const size_t hist_bytes = hist_bytes_of(K, P);
     c->bits = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
     c->generic = p.KT < 0 || P > kMaxP || dbg_env("BMM_DEBUG_GENERIC") != nullptr;
     if (!c->generic) {

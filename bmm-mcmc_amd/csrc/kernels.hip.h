@@ -31,8 +31,9 @@ namespace bmm {
 typedef __attribute__((address_space(3))) double lds_f64;  // LDS-qualified, keeps ds_read under volatile
 
 constexpr int kMaxP = 128;      // fast path: 4 bit-words per observation
-constexpr int kMaxG = (kMaxP + kGroupW - 1) / kGroupW;  // lookup groups on the fast path
-constexpr int kChunkP = kMaxP / kGroupW * kGroupW;      // features per table-building chunk: whole groups
+constexpr int lcm_(int a, int b) { int x = a; while (x % b) x += a; return x; }
+// features per table-building chunk: whole groups of every width
+constexpr int kChunkP = kMaxP / lcm_(lcm_(kGroupW, kGroupWAlt), kGroupWm) * lcm_(lcm_(kGroupW, kGroupWAlt), kGroupWm);
 constexpr int kMaxCats = 64;    // fast path: clusters (+ the DP's new-cluster option)
 constexpr int kMaxCatsAny = 1024;  // generic path
 
@@ -41,26 +42,29 @@ enum : int { MODE_COLLAPSED = 0, MODE_DP = 1, MODE_SB = 2, MODE_FULL = 3 };
 __host__ __device__ inline bool explicit_params(int mode) { return mode == MODE_SB || mode == MODE_FULL; }
 
 // Layout of the table image in global memory, in doubles:
-//   Tp  [G][KT][16]   group tables against the full statistics; group 0 carries the category's
+//   Tp  [G][KT][M]    group tables against the full statistics (M = 2^W, W the shape's group width:
+//                     ChainParams::W); group 0 carries the category's
 //                     prior / weight term Cp, so a score is just the sum of G entries
 //   Cp  [KT]          that term on its own (kept for inspection; the kernels do not read it)
 //   Cm  [KT]          ... with the scored observation removed from its own cluster
 //   Nk  [KT] int32    (two per double slot, padded to an even number of doubles)
 //   E   [256]         2^(j/256), the table of the spec's expw_ (read per lane in the draw)
-//   Tm  [G][KT][16]   group tables with the observation's own contribution removed, Cm in group 0
-//                     (not SB)
+//   Tm  [Gm][KT][Mm]  group tables with the observation's own contribution removed, Cm in group 0
+//                     (not SB); narrower groups, Mm = 2^kGroupWm entries each; Gm padded with all-zero
+//                     groups to a multiple of kOwnSub
 // A workgroup copies the head (Tp..Nk) into LDS, and Tm too when both fit in 160 KiB;
 // otherwise Tm is gathered from global memory (L2-resident, 1/K of the lookups).
 struct TableLayout {
-    int G, KT, has_minus;
+    int G, KT, Gm, M;  // Gm = 0: no own-cluster tables; M = entries per group of Tp
     __host__ __device__ int tp() const { return 0; }
-    __host__ __device__ int cp() const { return G * KT * kGroupM; }
+    __host__ __device__ int cp() const { return G * KT * M; }
     __host__ __device__ int cm() const { return cp() + KT; }
     __host__ __device__ int nk() const { return cm() + KT; }
     __host__ __device__ int et() const { return nk() + (KT + 1) / 2 + (((KT + 1) / 2) & 1); }
     __host__ __device__ int tm() const { return et() + 256; }
     __host__ __device__ int head() const { return tm(); }
-    __host__ __device__ int doubles() const { return tm() + (has_minus ? G * KT * kGroupM : 0); }
+    __host__ __device__ int gm_pad() const { return (Gm + kOwnSub - 1) / kOwnSub * kOwnSub; }
+    __host__ __device__ int doubles() const { return tm() + gm_pad() * KT * kGroupMm; }
 };
 
 struct ChainParams {
@@ -68,7 +72,8 @@ struct ChainParams {
     int64_t N;          // observations held by this chain object (a shard, or all of them)
     int64_t Ntot;       // observations of the whole chain (= N unless the chain is sharded over ranks)
     int64_t obs0;       // global index of local observation 0 (keys the per-observation Philox counter)
-    int P, G;
+    int P, W, G, Gm;    // features; features per lookup group of the tables (bmm_spec.h); groups of the
+                        // tables, of the own-cluster tables
     int K;              // labels (K or maxK)
     int Kc;             // categories = K (+1 for DP)
     int KT;             // Kc rounded up to the kernel's accumulator count
@@ -76,6 +81,9 @@ struct ChainParams {
     int sample_alpha;
     uint64_t seed;
 };
+__host__ __device__ inline TableLayout layout_of(const ChainParams& p, bool own_tables) {
+    return TableLayout{p.G, p.KT, own_tables ? p.Gm : 0, 1 << p.W};
+}
 
 // The integer delta accumulators exist kDeltaReps times (replica r of dS at dS + r*K*P, of dNk at
 // dNk + r*K).  Workgroup b of a launch adds into replica b % kDeltaReps: at the end of a short
@@ -132,14 +140,25 @@ __device__ __forceinline__ double update_alpha_wave(double alpha_old, double a, 
 // ---------------------------------------------------------------------------------
 // e1/e0 hold the `pc` features of one chunk; its `gc` groups start at global group g0
 // `c` is the category's constant term: it goes into the entries of global group 0
-__device__ __forceinline__ void write_group_tables(const double* e1, const double* e0, int pc, int g0, int gc,
+template <int W>
+__device__ __forceinline__ void write_group_tables_w(const double* e1, const double* e0, int pc, int g0, int gc,
                                                    int KT, int k, double c, double* T) {
-    for (int idx = threadIdx.x; idx < gc * kGroupM; idx += blockDim.x) {
-        const int g = idx / kGroupM;
-        const unsigned m = idx % kGroupM;
-        const double t = group_entry(e1, e0, g, pc, m);
-        T[((size_t)(g0 + g) * KT + k) * kGroupM + m] = g0 + g == 0 ? c + t : t;
+    constexpr int M = 1 << W;
+    for (int idx = threadIdx.x; idx < gc * M; idx += blockDim.x) {
+        const int g = idx / M;
+        const unsigned m = idx % M;
+        const double t = group_entry(e1, e0, g, pc, m, W);
+        T[((size_t)(g0 + g) * KT + k) * M + m] = g0 + g == 0 ? c + t : t;
     }
+}
+
+// W = the shape's width (kGroupW or kGroupWAlt) or the own-cluster tables' kGroupWm; uniform
+__device__ __forceinline__ void write_group_tables(int W, const double* e1, const double* e0, int pc, int c0,
+                                                   int KT, int k, double c, double* T) {
+    const int g0 = c0 / W, gc = (pc + W - 1) / W;
+    if (W == kGroupW) write_group_tables_w<kGroupW>(e1, e0, pc, g0, gc, KT, k, c, T);
+    else if (W == kGroupWAlt) write_group_tables_w<kGroupWAlt>(e1, e0, pc, g0, gc, KT, k, c, T);
+    else write_group_tables_w<kGroupWm>(e1, e0, pc, g0, gc, KT, k, c, T);
 }
 
 __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
                                                       double* __restrict__ tab) {
     __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP], cst[2];
     const int k = blockIdx.x;
-    const TableLayout L{p.G, p.KT, 1};
+    const TableLayout L = layout_of(p, true);
     const int P = p.P;
     const bool is_label = k < p.K;
     // 320 threads: the first 128 compute the full-statistics terms of feature d, the next 128 its
@@ -214,8 +233,8 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
             S[(size_t)k * P + d] = s;
             delta_clear(dS, (size_t)k * P + d, KP);
         }
-        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst[0], tab + L.tp());
-        write_group_tables(m1, m0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst[1], tab + L.tm());
+        write_group_tables(p.W, e1, e0, pc, c0, p.KT, k, cst[0], tab + L.tp());
+        write_group_tables(kGroupWm, m1, m0, pc, c0, p.KT, k, cst[1], tab + L.tm());
         __syncthreads();
     }
     if (is_label && threadIdx.x == 0) {  // every thread read the old pair before the barriers above
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
     // X and log theta for feature d while threads 128-255 draw Y and log(1 - theta): half the latency
     __shared__ double e1[kMaxP], e0[kMaxP], gam[2][kMaxP], cst;
     const int k = blockIdx.x;
-    const TableLayout L{p.G, p.KT, 0};
+    const TableLayout L = layout_of(p, false);
     const int P = p.P, K = p.K;
     const bool is_label = k < K;
     const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
             if (half == 0) e1[dl] = t; else e0[dl] = t;
         }
         __syncthreads();
-        write_group_tables(e1, e0, pc, c0 / kGroupW, (pc + kGroupW - 1) / kGroupW, p.KT, k, cst, tab + L.tp());
+        write_group_tables(p.W, e1, e0, pc, c0, p.KT, k, cst, tab + L.tp());
         __syncthreads();
     }
     if (k == 0) tab[L.et() + threadIdx.x] = exp256_table()[threadIdx.x];  // 256 threads
@@ -503,15 +522,10 @@ __device__ __forceinline__ void put_stage(uint32_t v, int h, uint32_t& b0, uint3
     b2 |= w == 2 ? sh : 0u;
     b3 |= w == 3 ? sh : 0u;
 }
-// The kGroupW-bit field of lookup group g (bits [g*kGroupW, (g+1)*kGroupW) of the observation's 128-bit
-// pattern); a field may straddle two words.  g uniform.
+// Word w of the observation's 128-bit pattern (w uniform; past the last word: 0).  The field of lookup
+// group g, bits [g*W, (g+1)*W), may straddle two words.
 __device__ __forceinline__ uint32_t word_of(int w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
     return w == 0 ? b0 : (w == 1 ? b1 : (w == 2 ? b2 : (w == 3 ? b3 : 0u)));
-}
-__device__ __forceinline__ unsigned group_field(int g, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
-    const int o = g * kGroupW, w = o >> 5;
-    return __builtin_amdgcn_alignbit(word_of(w + 1, b0, b1, b2, b3), word_of(w, b0, b1, b2, b3), o & 31) &
-           (unsigned)(kGroupM - 1);
 }
 
 // Sufficient-statistic deltas of one wave's movers into the workgroup's LDS histogram (integer LDS
@@ -693,8 +707,10 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #endif
 // EMIT: the launch also writes the draw's weights and their total (a.wts, a.wtot) for the probability
 // hand-off to the host's relabelling; a twin instantiation, so that the plain kernel carries no branch.
-template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false>
+// GW: features per lookup group of the tables (the shape's width, ChainParams::W).
+template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false, int GW = kGroupW>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    constexpr int GM = 1 << GW;  // entries per group table
     static_assert(SPLIT == 1 || (SPLIT == 2 && BITS && MINUS != 2 && KT % 2 == 0), "split form");
     constexpr int SB = BITS ? 32 : STG;  // start bits of the lookup groups one stage scores
     constexpr int KH = KT / SPLIT;      // accumulators per lane
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     DIAG(const unsigned long long d_entry = diag_stamp();)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool has_minus = MINUS != 0;
-    const TableLayout L{p.G, KT, has_minus ? 1 : 0};
+    const TableLayout L{p.G, KT, has_minus ? p.Gm : 0, GM};
     double* const lds = reinterpret_cast<double*>(smem);
     const int lds_doubles = MINUS == 1 ? L.doubles() : L.head();
     const volatile lds_f64* const Tp = (const volatile lds_f64*)(lds + L.tp());
@@ -821,23 +837,34 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         for (;;) {
             const int zoc = zo < 0 ? 0 : zo;
             double acc_own = 0.0;
-            if (MINUS == 2) {
-                // own-cluster ("minus self") tables too big for LDS beside Tp: gathered from global memory
-                // (L2-resident, one entry per group: 1/K of the lookups), all of a tile's gathers in flight
-                // together, in two halves, before the accumulators are live; summed in group order
+            if (MINUS != 0) {
+                // the observation's own cluster is scored from the "minus self" tables: one entry per (narrow)
+                // group, a per-lane gather -- from LDS (MINUS = 1), or from global memory when they are too big
+                // to sit there beside Tp (MINUS = 2: L2-resident) -- before the accumulators are live, kOwnSub
+                // groups per round: their fields are the low bits of a copy of the pattern that is shifted
+                // down between rounds, their gathers are in flight together and summed in group order.  The
+                // table image is padded with zero groups to whole rounds (bits past P are zero, so a padding
+                // group adds its entry 0 = 0.0).
+                uint32_t r0 = b0, r1 = b1, r2 = b2, r3 = b3;
+                constexpr int RB = kOwnSub * kGroupWm;  // bits per round
+                static_assert(RB < 32, "a round's fields come out of one word");
+                const int rounds = (p.Gm + kOwnSub - 1) / kOwnSub;
+                size_t at0 = (size_t)zoc * kGroupMm;
+#pragma unroll 1
+                for (int it = 0; it < rounds; ++it) {
+                    double ow[kOwnSub];
 #pragma unroll
-                for (int g0 = 0; g0 < kMaxG; g0 += (kMaxG + 1) / 2) {
-                    double ow[(kMaxG + 1) / 2];
-#pragma unroll
-                    for (int u = 0; u < (kMaxG + 1) / 2; ++u) {
-                        const int g = g0 + u;
-                        ow[u] = 0.0;
-                        if (g < kMaxG && g < G)
-                            ow[u] = TmG[((size_t)g * KT + zoc) * kGroupM + group_field(g, b0, b1, b2, b3)];
+                    for (int v = 0; v < kOwnSub; ++v) {
+                        const size_t at = at0 + (size_t)v * KT * kGroupMm + ((r0 >> (v * kGroupWm)) & (unsigned)(kGroupMm - 1));
+                        ow[v] = MINUS == 1 ? TmL[at] : TmG[at];
                     }
+                    r0 = __builtin_amdgcn_alignbit(r1, r0, RB);
+                    r1 = __builtin_amdgcn_alignbit(r2, r1, RB);
+                    r2 = __builtin_amdgcn_alignbit(r3, r2, RB);
+                    r3 >>= RB;
+                    at0 += (size_t)kOwnSub * KT * kGroupMm;
 #pragma unroll
-                    for (int u = 0; u < (kMaxG + 1) / 2; ++u)
-                        if (g0 + u < kMaxG && g0 + u < G) acc_own = acc_own + ow[u];
+                    for (int v = 0; v < kOwnSub; ++v) acc_own = acc_own + ow[v];
                 }
             }
             // the previous tile's labels go out here, ahead of this iteration's stage loads in
@@ -872,16 +899,14 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 const uint32_t cur = word_of(wd, b0, b1, b2, b3), nxt = word_of(wd + 1, b0, b1, b2, b3);
                 // the next tile's previous labels ride along with its first stage
                 if (has_next && h == 0 && a.z_in) zo_next = a.z_in[npos.ic];
-                const int g_lo = (SB * h + kGroupW - 1) / kGroupW;
-                int g_hi = (SB * (h + 1) + kGroupW - 1) / kGroupW;
+                const int g_lo = (SB * h + GW - 1) / GW;
+                int g_hi = (SB * (h + 1) + GW - 1) / GW;
                 g_hi = g_hi < G ? g_hi : G;
 #pragma unroll 1
                 for (int g = g_lo; g < g_hi; ++g) {
-                    const unsigned nib = __builtin_amdgcn_alignbit(nxt, cur, (unsigned)(g * kGroupW - 32 * wd)) &
-                                         (unsigned)(kGroupM - 1);
-                    const volatile lds_f64* row = Tp + (((size_t)g * KT + kb) * kGroupM + nib);
-                    double own = 0.0;
-                    if (MINUS == 1) own = TmL[((size_t)g * KT + zoc) * kGroupM + nib];
+                    const unsigned nib = __builtin_amdgcn_alignbit(nxt, cur, (unsigned)(g * GW - 32 * wd)) &
+                                         (unsigned)(GM - 1);
+                    const volatile lds_f64* row = Tp + (((size_t)g * KT + kb) * GM + nib);
 #pragma unroll
                     for (int c0 = 0; c0 < KH; c0 += CH) {
                         double tv[CH];
@@ -890,13 +915,12 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                         // waves' adds (+2 % measured; the int32 pipeline and the two-lane form lose 2-4 %)
                         if (BITS && SPLIT == 1) __builtin_amdgcn_s_setprio(BMM_LOOKUP_PRIO);
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * kGroupM];
+                        for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * GM];
                         if (BITS && SPLIT == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                         for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
                         if (CH < KH) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
                     }
-                    if (MINUS == 1) acc_own = acc_own + own;
                 }
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_score += n_ - d_t; d_t = n_; })
                 if (!BITS && has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
@@ -998,17 +1022,16 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 // Slow next to the resident kernel; it exists so that every shape the reference accepts runs.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned field_from_x(const int32_t* X, const uint32_t* Xb, int64_t N, int P,
-                                                  int64_t i, int g) {
+                                                  int64_t i, int g, int GW) {
     if (Xb) {  // bit planes, any number of words: the field may straddle two of them
-        const int o = g * kGroupW, w = o >> 5, sh = o & 31, W = (P + 31) >> 5;
+        const int o = g * GW, w = o >> 5, sh = o & 31, W = (P + 31) >> 5;
         uint32_t v = Xb[(int64_t)w * N + i] >> sh;
-        if (sh + kGroupW > 32 && w + 1 < W) v |= Xb[(int64_t)(w + 1) * N + i] << (32 - sh);
-        return v & (unsigned)(kGroupM - 1);
+        if (sh + GW > 32 && w + 1 < W) v |= Xb[(int64_t)(w + 1) * N + i] << (32 - sh);
+        return v & (unsigned)((1 << GW) - 1);
     }
     unsigned nib = 0;
-#pragma unroll
-    for (int j = 0; j < kGroupW; ++j) {
-        const int d = g * kGroupW + j;
+    for (int j = 0; j < GW; ++j) {
+        const int d = g * GW + j;
         if (d < P) nib |= ((unsigned)X[i + (int64_t)d * N] & 1u) << j;
     }
     return nib;
@@ -1017,7 +1040,8 @@ __device__ __forceinline__ unsigned field_from_x(const int32_t* X, const uint32_
 __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, ResampleArgs a, double* scr,
                                                           int64_t stride) {
     const bool has_minus = !explicit_params(p.mode);
-    const TableLayout L{p.G, p.KT, has_minus ? 1 : 0};
+    const TableLayout L = layout_of(p, has_minus);
+    const int GM = L.M;
     const double* const Tp = a.tab + L.tp();
     const double* const Tm = a.tab + L.tm();
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(a.tab + L.nk());
@@ -1038,18 +1062,18 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
         const int zoc = zo < 0 ? 0 : zo;
         double acc_own = 0.0;
         if (has_minus)
-            for (int g = 0; g < G; ++g)
-                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupM + field_from_x(a.X, a.Xb, p.N, P, i, g)];
+            for (int g = 0; g < p.Gm; ++g)
+                acc_own = acc_own + Tm[((size_t)g * KT + zoc) * kGroupMm + field_from_x(a.X, a.Xb, p.N, P, i, g, kGroupWm)];
         double m = neg_inf();
         for (int k0 = 0; k0 < Kc; k0 += 16) {
             double acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
             for (int g = 0; g < G; ++g) {
-                const double* row = Tp + ((size_t)g * KT + k0) * kGroupM + field_from_x(a.X, a.Xb, p.N, P, i, g);
+                const double* row = Tp + ((size_t)g * KT + k0) * GM + field_from_x(a.X, a.Xb, p.N, P, i, g, p.W);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (k0 + j < Kc) acc[j] = acc[j] + row[j * kGroupM];
+                    if (k0 + j < Kc) acc[j] = acc[j] + row[j * GM];
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -1127,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_probs_finish(ChainParams p, const doubl
                                                       const double* __restrict__ wts,
                                                       const double* __restrict__ wtot, int64_t lo, int64_t hi,
                                                       double* __restrict__ probs) {
-    const TableLayout L{p.G, p.KT, !explicit_params(p.mode) ? 1 : 0};
+    const TableLayout L = layout_of(p, !explicit_params(p.mode));
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(tab + L.nk());
     int new_label = -1;
     if (p.mode == MODE_DP)

@@ -74,8 +74,13 @@ extern "C" {
 #define BMM_NA_INTEGER (-2147483647 - 1)
 
 const char* bmm_last_error(void);
-/* features per lookup group of the spec arithmetic (DESIGN.md "Numerics") */
+/* features per lookup group of the spec arithmetic (DESIGN.md "Numerics"): of the tables against the full
+ * statistics (preferred width; _for: the width the shape runs at -- narrower when its table image would not
+ * fit in LDS otherwise; a pure function of its arguments, -1 for invalid ones), and of the own-cluster
+ * ("minus self") tables */
 int bmm_spec_group_width(void);
+int bmm_spec_group_width_own(void);
+int bmm_spec_group_width_for(int sampler, int K, int P);
 /* library default batch size for N observations (used when batch <= 0): N/8 for the finite
  * sampler, N/16 for the DP sampler (rounded up to a multiple of 3 * 2^18 above that: whole rounds of
  * 256 workgroups of 1024, 768 or 512 threads), N for stick-breaking and full; depends on nothing

@@ -11,12 +11,33 @@
 #include <string.h>
 #include <time.h>
 
-#define GW 4  /* features per lookup group; must equal bmm::kGroupW */
-#define GM 16 /* 1 << GW */
+#define GW 5  /* features per lookup group of the tables against the full statistics (= bmm::kGroupW) ... */
+#define GW_ALT 4 /* ... unless the shape's table image is too big for that (oracle_group_width_for) */
+#define GWM 3 /* ... of the own-cluster ("minus self") tables; = bmm::kGroupWm */
+#define GMM (1 << GWM)
 
 static __thread char g_err[256];
 const char* oracle_last_error(void) { return g_err; }
 int oracle_group_width(void) { return GW; }
+int oracle_group_width_own(void) { return GWM; }
+/* The spec's rule for the group width of a shape (DESIGN.md "Numerics"; sampler 0 collapsed, 1 DP, 2
+ * stick-breaking, 3 full): 5 features per group when the whole table image of the shape -- tables of
+ * 32-entry groups for the categories rounded up to a supported accumulator count, the constants, the
+ * cluster sizes, the 256-entry exponential table, for the counting samplers the own-cluster tables (groups
+ * of 3, padded to a multiple of 6 groups) -- and the integer histogram fit in 160 KiB; 4 otherwise. */
+int oracle_group_width_for(int sampler, int K, int P) {
+    static const int kts[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    const int cats = sampler == 1 ? K + 1 : K;
+    int KT = -1;
+    for (unsigned q = 0; q < sizeof kts / sizeof kts[0]; ++q) if (kts[q] >= cats) { KT = kts[q]; break; }
+    if (KT < 0 || P > 128) return GW_ALT;
+    const int counting = sampler == 0 || sampler == 1;
+    const long G = (P + GW - 1) / GW, Gm = ((P + GWM - 1) / GWM + 5) / 6 * 6;
+    const long nk = (KT + 1) / 2 + (((KT + 1) / 2) & 1);
+    long doubles = G * KT * (1 << GW) + 2 * KT + nk + 256 + (counting ? Gm * KT * GMM : 0);
+    long bytes = doubles * 8 + ((long)K * P + K + 4) * 4;
+    return bytes <= 163840 ? GW : GW_ALT;
+}
 
 static int fail(const char* msg) {
     snprintf(g_err, sizeof g_err, "%s", msg);
@@ -264,11 +285,14 @@ static int scores_to_weights(const double* score, int n, double* w) {
 /* ------------------------------------------------------------------ spec tables */
 /* Group table of one cluster from counts (n observations, s[d] ones), optionally
  * with the scored observation's own contribution removed (minus = 1: n-1, and s-1
- * on the x=1 side).  T has G*GM entries.  Combinations no member can exhibit get 0. */
-static void counts_group_table(double beta, double gamma, int P, int G, int64_t n, const int32_t* s,
+ * on the x=1 side).  Groups of W features: T has G * 2^W entries, G = ceil(P / W) (the callers use GW for
+ * the full tables and GWM for the minus-self ones).  Combinations no member can exhibit get 0. */
+static void counts_group_table(double beta, double gamma, int P, int W, int64_t n, const int32_t* s,
                                int minus, double* e1, double* e0, double* T) {
+    const int G = (P + W - 1) / W;
+    const unsigned M = 1u << W;
     int64_t ne = n - minus;
-    if (ne <= 0) { memset(T, 0, sizeof(double) * (size_t)G * GM); return; }
+    if (ne <= 0) { memset(T, 0, sizeof(double) * (size_t)G * M); return; }
     double den = oracle_log((beta + gamma) + (double)ne);
     for (int d = 0; d < P; ++d) {
         int64_t s1 = (int64_t)s[d] - minus;
@@ -276,44 +300,47 @@ static void counts_group_table(double beta, double gamma, int P, int G, int64_t 
         e0[d] = s[d] > ne ? 0.0 : oracle_log((gamma + (double)ne) - (double)s[d]) - den;
     }
     for (int g = 0; g < G; ++g)
-        for (unsigned m = 0; m < GM; ++m) {
+        for (unsigned m = 0; m < M; ++m) {
             double t = 0.0;
-            for (int j = 0; j < GW; ++j) {
-                int d = g * GW + j;
+            for (int j = 0; j < W; ++j) {
+                int d = g * W + j;
                 if (d < P) t = t + (((m >> j) & 1u) ? e1[d] : e0[d]);
             }
-            T[g * GM + m] = t;
+            T[g * M + m] = t;
         }
 }
-static void theta_group_table(int P, int G, int K, int k, const double* theta /*K x P colmajor*/,
+static void theta_group_table(int P, int W, int K, int k, const double* theta /*K x P colmajor*/,
                               double* T) {
+    const int G = (P + W - 1) / W;
+    const unsigned M = 1u << W;
     for (int g = 0; g < G; ++g)
-        for (unsigned m = 0; m < GM; ++m) {
+        for (unsigned m = 0; m < M; ++m) {
             double t = 0.0;
-            for (int j = 0; j < GW; ++j) {
-                int d = g * GW + j;
+            for (int j = 0; j < W; ++j) {
+                int d = g * W + j;
                 if (d < P) {
                     double th = theta[k + (size_t)d * K];
                     t = t + (((m >> j) & 1u) ? oracle_log(th) : oracle_log(1.0 - th));
                 }
             }
-            T[g * GM + m] = t;
+            T[g * M + m] = t;
         }
 }
 /* score = ((C + T[0]) + T[1]) + ...: the category's constant term enters first (the HIP
  * path stores C + T[0][m] as the entries of group 0) */
-static inline double table_sum(double C, const double* T, const uint8_t* nib, int G) {
+static inline double table_sum(double C, const double* T, const uint8_t* nib, int G, int M) {
     double acc = C;
-    for (int g = 0; g < G; ++g) acc = acc + T[g * GM + nib[g]];
+    for (int g = 0; g < G; ++g) acc = acc + T[g * M + nib[g]];
     return acc;
 }
-/* nibbles of every observation: nib[i*G + g] = sum_j x[i, g*GW+j] << j */
-static uint8_t* pack_nibbles(const int32_t* X, int64_t N, int P, int G) {
+/* group fields of every observation, W features per group: nib[i*G + g] = sum_j x[i, g*W+j] << j */
+static uint8_t* pack_nibbles(const int32_t* X, int64_t N, int P, int W) {
+    const int G = (P + W - 1) / W;
     uint8_t* nib = (uint8_t*)calloc((size_t)N * G, 1);
     if (!nib) return NULL;
     for (int d = 0; d < P; ++d) {
         const int32_t* col = X + (size_t)d * N;
-        int g = d / GW, j = d % GW;
+        int g = d / W, j = d % W;
         for (int64_t i = 0; i < N; ++i) nib[(size_t)i * G + g] |= (uint8_t)((col[i] & 1) << j);
     }
     return nib;
@@ -368,29 +395,31 @@ static void count_stats(const int32_t* X, int64_t N, int P, const int32_t* z, in
 void oracle_collapsed_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i,
                                 int K, double alpha, double beta, double gamma, double* score,
                                 double* norm) {
-    int G = (P + GW - 1) / GW;
+    const int gw = oracle_group_width_for(0, K, P), GM = 1 << gw;
+    int G = (P + gw - 1) / gw, Gm = (P + GWM - 1) / GWM;
     int32_t* Nk = (int32_t*)malloc(sizeof(int32_t) * K);
     int32_t* S = (int32_t*)malloc(sizeof(int32_t) * (size_t)K * P);
     double* e1 = (double*)malloc(sizeof(double) * P * 2);
-    double* T = (double*)malloc(sizeof(double) * (size_t)G * GM);
+    double* T = (double*)malloc(sizeof(double) * ((size_t)G * GM + (size_t)Gm * GMM));
     double* w = (double*)malloc(sizeof(double) * K);
-    uint8_t* nib = pack_nibbles(X, N, P, G);
+    uint8_t* nib = pack_nibbles(X, N, P, gw);
+    uint8_t* nibm = pack_nibbles(X, N, P, GWM);
     count_stats(X, N, P, z, K, Nk, S);
     int zo = z[i] - 1;
     double ldN = oracle_log((double)(N - 1) + alpha);
     for (int k = 0; k < K; ++k) {
         int minus = (k == zo);
         int64_t ne = Nk[k] - minus;
-        counts_group_table(beta, gamma, P, G, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
+        counts_group_table(beta, gamma, P, minus ? GWM : gw, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
         double C = ne > 0 ? oracle_log((double)ne + alpha / (double)K) - ldN : O_NEG_INF;
-        score[k] = table_sum(C, T, nib + (size_t)i * G, G);
+        score[k] = minus ? table_sum(C, T, nibm + (size_t)i * Gm, Gm, GMM) : table_sum(C, T, nib + (size_t)i * G, G, GM);
     }
     if (scores_to_weights(score, K, w)) {
         double tot = 0.0;
         for (int k = 0; k < K; ++k) tot = tot + w[k];
         for (int k = 0; k < K; ++k) norm[k] = w[k] / tot;
     }
-    free(Nk); free(S); free(e1); free(T); free(w); free(nib);
+    free(Nk); free(S); free(e1); free(T); free(w); free(nib); free(nibm);
 }
 
 /* collapsed_gibbs_dp.cpp:71,102-106,140-186 for one observation; clusters = labels 1..K */
@@ -430,22 +459,24 @@ static double dp_new_score(double alpha, double beta, double gamma, int P, doubl
 
 void oracle_dp_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, int64_t i, int K,
                          double alpha, double beta, double gamma, double* logw, double* norm) {
-    int G = (P + GW - 1) / GW;
+    const int gw = oracle_group_width_for(1, K, P), GM = 1 << gw;
+    int G = (P + gw - 1) / gw, Gm = (P + GWM - 1) / GWM;
     int32_t* Nk = (int32_t*)malloc(sizeof(int32_t) * K);
     int32_t* S = (int32_t*)malloc(sizeof(int32_t) * (size_t)K * P);
     double* e1 = (double*)malloc(sizeof(double) * P * 2);
-    double* T = (double*)malloc(sizeof(double) * (size_t)G * GM);
+    double* T = (double*)malloc(sizeof(double) * ((size_t)G * GM + (size_t)Gm * GMM));
     double* w = (double*)malloc(sizeof(double) * (K + 1));
-    uint8_t* nib = pack_nibbles(X, N, P, G);
+    uint8_t* nib = pack_nibbles(X, N, P, gw);
+    uint8_t* nibm = pack_nibbles(X, N, P, GWM);
     count_stats(X, N, P, z, K, Nk, S);
     int zo = z[i] - 1;
     double ldN = oracle_log((double)(N - 1) + alpha);
     for (int k = 0; k < K; ++k) {
         int minus = (k == zo);
         int64_t ne = Nk[k] - minus;
-        counts_group_table(beta, gamma, P, G, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
+        counts_group_table(beta, gamma, P, minus ? GWM : gw, Nk[k], S + (size_t)k * P, minus, e1, e1 + P, T);
         double C = ne > 0 ? oracle_log((double)ne) - ldN : O_NEG_INF;
-        logw[k] = table_sum(C, T, nib + (size_t)i * G, G);
+        logw[k] = minus ? table_sum(C, T, nibm + (size_t)i * Gm, Gm, GMM) : table_sum(C, T, nib + (size_t)i * G, G, GM);
     }
     logw[K] = dp_new_score(alpha, beta, gamma, P, ldN) + 0.0;
     if (scores_to_weights(logw, K + 1, w)) {
@@ -453,7 +484,7 @@ void oracle_dp_cond_spec(const int32_t* X, int64_t N, int P, const int32_t* z, i
         for (int k = 0; k <= K; ++k) tot = tot + w[k];
         for (int k = 0; k <= K; ++k) norm[k] = w[k] / tot;
     }
-    free(Nk); free(S); free(e1); free(T); free(w); free(nib);
+    free(Nk); free(S); free(e1); free(T); free(w); free(nib); free(nibm);
 }
 
 /* stickbreaking.cpp:75-105 for one observation */
@@ -475,13 +506,14 @@ void oracle_sb_cond_literal(const int32_t* X, int64_t N, int P, int64_t i, int K
 }
 void oracle_sb_cond_spec(const int32_t* X, int64_t N, int P, int64_t i, int K, const double* pi,
                          const double* theta, double* score, double* norm) {
-    int G = (P + GW - 1) / GW;
+    const int gw = oracle_group_width_for(2, K, P), GM = 1 << gw;
+    int G = (P + gw - 1) / gw;
     double* T = (double*)malloc(sizeof(double) * (size_t)G * GM);
     double* w = (double*)malloc(sizeof(double) * K);
-    uint8_t* nib = pack_nibbles(X, N, P, G);
+    uint8_t* nib = pack_nibbles(X, N, P, gw);
     for (int k = 0; k < K; ++k) {
-        theta_group_table(P, G, K, k, theta, T);
-        score[k] = table_sum(oracle_log(pi[k]), T, nib + (size_t)i * G, G);
+        theta_group_table(P, gw, K, k, theta, T);
+        score[k] = table_sum(oracle_log(pi[k]), T, nib + (size_t)i * G, G, GM);
     }
     if (scores_to_weights(score, K, w)) {
         double tot = 0.0;
@@ -743,7 +775,8 @@ static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, 
                      double gamma, double a, double b, int burnin, uint64_t seed, double* pi_out,
                      int32_t* z_out, double* theta_out, double* alpha_out) {
     if (nsamples < 1 || burnin < 0 || burnin > nsamples) return fail("bad nsamples/burnin");
-    int S = nsamples - burnin, G = (P + GW - 1) / GW;
+    const int gw = oracle_group_width_for(full ? 3 : 2, maxK, P), GM = 1 << gw;
+    int S = nsamples - burnin, G = (P + gw - 1) / gw;
     double* pi = (double*)malloc(sizeof(double) * maxK);
     double* theta = (double*)malloc(sizeof(double) * (size_t)maxK * P);
     double* alpha_sampled = (double*)malloc(sizeof(double) * nsamples);
@@ -754,7 +787,7 @@ static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, 
     int32_t* zcur = (int32_t*)malloc(sizeof(int32_t) * N);
     int32_t* ck = (int32_t*)malloc(sizeof(int32_t) * maxK);
     int32_t* Vkd = (int32_t*)malloc(sizeof(int32_t) * (size_t)maxK * P);
-    uint8_t* nib = literal ? NULL : pack_nibbles(X, N, P, G);
+    uint8_t* nib = literal ? NULL : pack_nibbles(X, N, P, gw);
     memcpy(pi, pi0, sizeof(double) * maxK);
     memcpy(theta, theta0, sizeof(double) * (size_t)maxK * P);
     if (alpha == 0) alpha_sampled[0] = 1; else for (int j = 0; j < nsamples; ++j) alpha_sampled[j] = alpha;
@@ -767,7 +800,7 @@ static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, 
     for (int j = 1; j < nsamples; ++j) {
         if (!literal)
             for (int k = 0; k < maxK; ++k) {
-                theta_group_table(P, G, maxK, k, theta, T + (size_t)k * G * GM);
+                theta_group_table(P, gw, maxK, k, theta, T + (size_t)k * G * GM);
                 C[k] = oracle_log(pi[k]);
             }
         for (int64_t i = 0; i < N; ++i) { /* :70-125 */
@@ -792,7 +825,7 @@ static int sb_common(int literal, int full, const int32_t* X, int64_t N, int P, 
                 pick = draw_index(s, maxK, u);
             } else {
                 for (int k = 0; k < maxK; ++k)
-                    s[k] = table_sum(C[k], T + (size_t)k * G * GM, nib + (size_t)i * G, G);
+                    s[k] = table_sum(C[k], T + (size_t)k * G * GM, nib + (size_t)i * G, G, GM);
                 pick = scores_to_weights(s, maxK, w) ? draw_index(w, maxK, u) : -1;
             }
             if (pick < 0) pick = (j > 1) ? zcur[i] : 0;
@@ -856,13 +889,13 @@ int oracle_full_run(const int32_t* X, int64_t N, int P, const double* pi0, const
 /* ------------------------------------------------------------------ sufficient-statistics chains */
 typedef struct {
     int sampler; /* 0 collapsed, 1 dp */
-    int64_t N; int P, K, G;  /* K = number of labels (K or maxK) */
+    int64_t N; int P, K, gw, G, Gm;  /* K = number of labels (K or maxK); groups of gw / of GWM features */
     const int32_t* X;
-    uint8_t* nib;
+    uint8_t* nib; uint8_t* nibm;
     int32_t* z;      /* current 0-based label, -1 unassigned */
     int32_t* znew;   /* batch scratch */
     int32_t* Nk; int32_t* S; /* K, K*P */
-    double* Tp; double* Tm;  /* K*G*GM each */
+    double* Tp; double* Tm;  /* K*G*GM, K*Gm*GMM */
     double* Cp; double* Cm;  /* K (+1 for dp new) */
     unsigned char* dirty;
     double* score; double* w; double* e;
@@ -873,33 +906,35 @@ typedef struct {
 } ochain;
 
 static void chain_free(ochain* c) {
-    free(c->nib); free(c->z); free(c->znew); free(c->Nk); free(c->S); free(c->Tp); free(c->Tm);
+    free(c->nib); free(c->nibm); free(c->z); free(c->znew); free(c->Nk); free(c->S); free(c->Tp); free(c->Tm);
     free(c->Cp); free(c->Cm); free(c->dirty); free(c->score); free(c->w); free(c->e);
 }
 static int chain_init(ochain* c, int sampler, const int32_t* X, int64_t N, int P, int K,
                       const int32_t* z0_1based, double alpha, double beta, double gamma, double a,
                       double b, int64_t batch, uint64_t seed) {
     memset(c, 0, sizeof *c);
-    c->sampler = sampler; c->N = N; c->P = P; c->K = K; c->G = (P + GW - 1) / GW; c->X = X;
+    c->sampler = sampler; c->N = N; c->P = P; c->K = K; c->gw = oracle_group_width_for(sampler, K, P);
+    c->G = (P + c->gw - 1) / c->gw; c->Gm = (P + GWM - 1) / GWM; c->X = X;
     c->beta = beta; c->gamma = gamma; c->a = a; c->b = b; c->seed = seed;
     c->batch = batch < 1 ? 1 : (batch > N ? N : batch);
     c->sample_alpha = (alpha == 0);
     c->alpha_cur = c->sample_alpha ? 1.0 : alpha;
-    size_t tg = (size_t)K * c->G * GM;
-    c->nib = pack_nibbles(X, N, P, c->G);
+    size_t tg = (size_t)K * c->G * ((size_t)1 << c->gw), tgm = (size_t)K * c->Gm * GMM;
+    c->nib = pack_nibbles(X, N, P, c->gw);
+    c->nibm = pack_nibbles(X, N, P, GWM);
     c->z = (int32_t*)malloc(sizeof(int32_t) * N);
     c->znew = (int32_t*)malloc(sizeof(int32_t) * N);
     c->Nk = (int32_t*)calloc(K, sizeof(int32_t));
     c->S = (int32_t*)calloc((size_t)K * P, sizeof(int32_t));
     c->Tp = (double*)calloc(tg, sizeof(double));
-    c->Tm = (double*)calloc(tg, sizeof(double));
+    c->Tm = (double*)calloc(tgm, sizeof(double));
     c->Cp = (double*)calloc(K + 1, sizeof(double));
     c->Cm = (double*)calloc(K + 1, sizeof(double));
     c->dirty = (unsigned char*)malloc(K);
     c->score = (double*)malloc(sizeof(double) * (K + 1));
     c->w = (double*)malloc(sizeof(double) * (K + 1));
     c->e = (double*)malloc(sizeof(double) * 2 * P);
-    if (!c->nib || !c->z || !c->znew || !c->Tp || !c->Tm) return fail("out of memory");
+    if (!c->nib || !c->nibm || !c->z || !c->znew || !c->Tp || !c->Tm) return fail("out of memory");
     memset(c->dirty, 1, K);
     for (int64_t i = 0; i < N; ++i) {
         int k = z0_1based ? z0_1based[i] - 1 : -1;
@@ -926,15 +961,16 @@ static void chain_apply(ochain* c, int64_t i, int zn) {
 }
 /* one batch [lo, hi) of sweep j against statistics frozen at batch start */
 static void chain_batch(ochain* c, int64_t lo, int64_t hi, uint32_t j) {
-    const int K = c->K, G = c->G, P = c->P;
-    const size_t tk = (size_t)G * GM;
+    const int K = c->K, G = c->G, Gm = c->Gm, P = c->P;
+    const int GM = 1 << c->gw;
+    const size_t tk = (size_t)G * GM, tkm = (size_t)Gm * GMM;
     const double alpha = c->alpha_cur;
     const double ldN = oracle_log((double)(c->N - 1) + alpha);
     int Kused = 0, new_label = -1;
     for (int k = 0; k < K; ++k) {
         if (c->dirty[k]) {
-            counts_group_table(c->beta, c->gamma, P, G, c->Nk[k], c->S + (size_t)k * P, 0, c->e, c->e + P, c->Tp + k * tk);
-            counts_group_table(c->beta, c->gamma, P, G, c->Nk[k], c->S + (size_t)k * P, 1, c->e, c->e + P, c->Tm + k * tk);
+            counts_group_table(c->beta, c->gamma, P, c->gw, c->Nk[k], c->S + (size_t)k * P, 0, c->e, c->e + P, c->Tp + k * tk);
+            counts_group_table(c->beta, c->gamma, P, GWM, c->Nk[k], c->S + (size_t)k * P, 1, c->e, c->e + P, c->Tm + k * tkm);
             c->dirty[k] = 0;
         }
         int64_t n = c->Nk[k];
@@ -951,10 +987,11 @@ static void chain_batch(ochain* c, int64_t lo, int64_t hi, uint32_t j) {
     if (c->sampler == 1) c->Cp[K] = dp_new_score(alpha, c->beta, c->gamma, P, ldN);
     for (int64_t i = lo; i < hi; ++i) {
         const uint8_t* nb = c->nib + (size_t)i * G;
+        const uint8_t* nbm = c->nibm + (size_t)i * Gm;
         const int zo = c->z[i];
         for (int k = 0; k < K; ++k) {
-            if (k == zo) c->score[k] = table_sum(c->Cm[k], c->Tm + k * tk, nb, G);
-            else c->score[k] = table_sum(c->Cp[k], c->Tp + k * tk, nb, G);
+            if (k == zo) c->score[k] = table_sum(c->Cm[k], c->Tm + k * tkm, nbm, Gm, GMM);
+            else c->score[k] = table_sum(c->Cp[k], c->Tp + k * tk, nb, G, GM);
         }
         if (c->sampler == 1) c->score[K] = c->Cp[K] + 0.0;
         int pick = scores_to_weights(c->score, ncat, c->w)

@@ -55,6 +55,8 @@ double oracle_update_alpha(double alpha_old, double a, double b, double N, int K
 void oracle_log_array(const double* x, double* y, int64_t n);
 void oracle_exp_array(const double* x, double* y, int64_t n);
 int oracle_group_width(void);
+int oracle_group_width_own(void);
+int oracle_group_width_for(int sampler, int K, int P); /* the spec's per-shape rule: 5, or 4 for big table images */
 
 /* ---- RNG-free conditionals of one observation (z is 1-based, i 0-based) ---- */
 /* literal = reference formula with glibc; spec = the build's table arithmetic. */

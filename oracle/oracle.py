@@ -61,6 +61,9 @@ def lib():
         L.oracle_time_sweeps.argtypes = [C.c_int, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                          C.c_int64, C.c_uint64, C.c_int]
         L.oracle_group_width.restype = C.c_int
+        L.oracle_group_width_own.restype = C.c_int
+        L.oracle_group_width_for.restype = C.c_int
+        L.oracle_group_width_for.argtypes = [C.c_int, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_spec_constants_match_oracle(oracle):
-    assert _capi.lib().bmm_spec_group_width() == oracle.lib().oracle_group_width() == 4
+    assert _capi.lib().bmm_spec_group_width() == oracle.lib().oracle_group_width()
+    assert _capi.lib().bmm_spec_group_width_own() == oracle.lib().oracle_group_width_own()
 
 
 def test_default_batch_policy():
@@ -96,3 +97,21 @@ def test_chain_summary_derives_what_plot_gibbs_plots():
     assert np.allclose(s["proportions"][3], [1 / 3, 2 / 3, 0.0])
     assert s["clusters"] == [1, 2]  # label 3 never exceeds 0.3; sample 1 (all ones) is not consulted
     assert np.isnan(s["theta"][2]).all() and np.array_equal(s["theta"][:2], theta[:2])
+
+
+def test_group_width_rule_is_the_oracles(oracle):
+    """the per-shape group width is part of the arithmetic: library and oracle state the rule independently"""
+    L, O = _capi.lib(), oracle.lib()
+    L.bmm_spec_group_width_for.restype = O.oracle_group_width_for.restype = __import__("ctypes").c_int
+    seen = set()
+    for sampler in range(4):
+        for K in (1, 2, 3, 4, 5, 12, 19, 20, 21, 24, 29, 30, 31, 32, 33, 40, 47, 48, 50, 56, 63, 64, 65, 100):
+            for P in (1, 5, 20, 31, 32, 33, 50, 64, 65, 96, 100, 101, 110, 127, 128, 129, 513):
+                w = L.bmm_spec_group_width_for(sampler, K, P)
+                assert w == O.oracle_group_width_for(sampler, K, P), (sampler, K, P)
+                seen.add(w)
+    assert seen == {4, 5}
+    assert L.bmm_spec_group_width_for(0, 20, 100) == 5 and L.bmm_spec_group_width_for(1, 30, 50) == 5  # C5, C3
+    assert L.bmm_spec_group_width_for(2, 50, 50) == 5 and L.bmm_spec_group_width_for(0, 3, 20) == 5    # C4, C2
+    assert L.bmm_spec_group_width_for(0, 20, 128) == 4 and L.bmm_spec_group_width_for(2, 64, 64) == 4
+    assert L.bmm_spec_group_width_for(7, 3, 3) == -1

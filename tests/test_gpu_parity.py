@@ -391,3 +391,39 @@ def test_unsupported_shapes_fail_loudly():
         bm.gibbs_collapsed(X, 5, 2000, seed=1)
     with pytest.raises(bm.BmmError, match="initialK"):
         bm.gibbs_collapsed(X, 5, 2, seed=1, initial_K=np.full(50, 3))
+
+
+# ---------------------------------------------------------------- the narrower group width (big table images)
+def test_shapes_whose_tables_need_the_narrower_groups(oracle):
+    """group width 4 instead of 5 where the 32-entry tables would not fit in LDS (bmm_spec_group_width_for):
+    own-cluster tables still resident (K=20, P=112), two lanes per observation (stick-breaking K=64, P=64),
+    and the emitting twin (sweep_probs) on such a shape -- all bit-equal to the oracle, which applies the
+    same rule on its own"""
+    from bmm_mcmc_amd import _capi
+    W = _capi.lib().bmm_spec_group_width_for
+    assert W(0, 20, 112) == 4 and W(2, 64, 64) == 4 and W(0, 20, 100) == 5
+    N, P, K = 5000, 112, 20
+    X, _, _, _ = synth(N, P, 5, 51)
+    z0 = _z0(N, K, 52)
+    for batch in (N, 700):
+        got = bm.gibbs_collapsed(X, 5, K, burnin=0, seed=3, batch=batch, initial_K=z0)
+        want = oracle.collapsed(X, z0, 5, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=3, batch=batch)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, batch)
+    with bm.Chain("collapsed", N, P, K, alpha=1.5, batch=N, seed=4) as ch:
+        assert ch.kernel_shape()["lds_bytes"] > 0            # resident, not the generic path
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        zb = ch.labels()
+        probs = ch.sweep_probs()
+    for i in (0, 1, 777, N - 1):
+        _, norm = oracle.collapsed_cond(X, zb, i, K, 1.5, 0.5, 0.5, spec=True)
+        assert np.array_equal(probs[i], norm)
+    N, P, K = 3000, 64, 64
+    X, _, _, _ = synth(N, P, 6, 53)
+    pi0, th0 = _sb_init(K, P, 2)
+    got = bm.gibbs_stickbreaking(X, 4, K, burnin=0, seed=5, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 4, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=5)
+    for k in ("z", "theta", "alpha", "pi"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
