@@ -277,16 +277,20 @@ def main():
                         "frac": gbps / HBM_PEAK_GBS})
             return out
         vpw = info.get("valu_inst_per_64_obs")
-        # LDS traffic the scoring cannot avoid: K*G group-table reads + G own-cluster reads + K reads of the
-        # exponential's table, 8 bytes each, per observation; peak 256 B/clk/CU x 256 CUs x 2.4 GHz
-        G4 = (P + 3) // 4
-        own = 0 if m["sampler"] in ("stickbreaking", "full") else G4
+        # LDS traffic the scoring cannot avoid: K*G group-table reads (G groups of the shape's width) + Gm
+        # own-cluster reads (groups of 3) + K reads of the exponential's table, 8 bytes each, per observation;
+        # peak 256 B/clk/CU x 256 CUs x 2.4 GHz
+        from bmm_mcmc_amd import _capi
+        code = {"collapsed": 0, "dp": 1, "stickbreaking": 2, "full": 3}[m["sampler"]]
+        gw = _capi.lib().bmm_spec_group_width_for(code, m["K"], P)
+        G = (P + gw - 1) // gw
+        own = 0 if m["sampler"] in ("stickbreaking", "full") else (P + _capi.lib().bmm_spec_group_width_own() - 1) // _capi.lib().bmm_spec_group_width_own()
         cats = m["K"] + (1 if m["sampler"] == "dp" else 0)
-        lds_tbps = (cats * G4 + own + cats) * 8 * N * steps / secs / 1e12
+        lds_tbps = (cats * G + own + cats) * 8 * N * steps / secs / 1e12
         lds_peak = 256 * 256 * 2.4e9 / 1e12
         out.update({"bound": "valu_f64_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
                     "hbm_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBS,
-                    "lds_TBps": lds_tbps, "lds_frac": lds_tbps / lds_peak,
+                    "lds_TBps": lds_tbps, "lds_frac": lds_tbps / lds_peak, "group_width": gw,
                     "layout": "bit planes: %d bytes per observation and sweep" % (bps // N)})
         if vpw:
             ginst = vpw * (N / 64.0) * steps / secs / 1e9
@@ -295,7 +299,7 @@ def main():
         else:
             out.update({"achieved": None, "frac": None})
         out["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 layout and is bound by "
-                       "what it does per observation on the CU -- K*ceil(P/4) LDS table reads + fp64 adds, K "
+                       "what it does per observation on the CU -- K*ceil(P/5) LDS table reads + fp64 adds, K "
                        "exponentials -- not by HBM.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, "
                        "profiles/) / launch time measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  lds_frac is "
                        "the same for the LDS reads the scoring cannot avoid against 256 B/clk/CU (the PMC passes "

@@ -4,10 +4,11 @@
 // matrix is handed over (ceil(P/32) 32-bit words per observation; the default) or as the N x P
 // int32 column-major matrix R hands over (lane i reads X[i + d*N]: a wave reads 256 contiguous
 // bytes per feature, packed to bits in registers as they arrive).  The per-cluster log-predictive
-// is K*ceil(P/4) LDS lookups into 16-entry group tables (one ds_read_b64 + one v_add_f64 per
-// cluster per 4 features; the category's constant term sits in group 0) instead of K*P
-// multiply-adds.  All 16 entries of a group sit in one 128-byte run, i.e. on 16 different bank
-// pairs, so the per-lane-indexed read is conflict-free.  Work is handed out per wave in chunks of 64
+// is K*ceil(P/W) LDS lookups into 2^W-entry group tables (one ds_read_b64 + one v_add_f64 per
+// cluster per W features, W = 5, or 4 for big table images: bmm_spec.h; the category's constant term
+// sits in group 0) instead of K*P multiply-adds; the observation's own cluster is scored from tables
+// of its own with groups of 3.  All entries of a group sit in one 256- (128-) byte run, i.e. on different
+// bank pairs, so the per-lane-indexed read is conflict-free.  Work is handed out per wave in chunks of 64
 // observations from a counter in LDS.  Sufficient-statistic changes are accumulated as integers in
 // LDS (a few movers: one at a time by the whole wave, one feature per lane; many: every mover lane
 // walks its own set bits) and flushed with one global integer atomic per touched cell per
@@ -855,7 +856,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                     double ow[kOwnSub];
 #pragma unroll
                     for (int v = 0; v < kOwnSub; ++v) {
-                        const size_t at = at0 + (size_t)v * KT * kGroupMm + ((r0 >> (v * kGroupWm)) & (unsigned)(kGroupMm - 1));
+                        // v_bfe_u32 by hand: the compiler turns the bit-field extract into shift + and + add
+                        // (three instructions where bfe + shift-add are two)
+                        unsigned f;
+                        asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(f) : "v"(r0), "n"(v * kGroupWm), "n"(kGroupWm));
+                        const size_t at = at0 + (size_t)v * KT * kGroupMm + f;
                         ow[v] = MINUS == 1 ? TmL[at] : TmG[at];
                     }
                     r0 = __builtin_amdgcn_alignbit(r1, r0, RB);
