@@ -6,6 +6,7 @@
 // the reference's (collapsed_gibbs.cpp:84-225, collapsed_gibbs_dp.cpp:98-283,
 // stickbreaking.cpp:66-236) with the per-observation loop replaced by batches.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen when a run spans devices
 
 #include <dlfcn.h>
@@ -486,17 +487,22 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
         }
         e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
         c->ev_used += 2;
-        HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    if (use_generic)
-        hipLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, c->p, a, c->dScratch,
-                           c->scratch_stride);
-    else if (emit)
-        hipLaunchKernelGGL(c->fn_emit, dim3(grid), dim3(c->NT_emit), c->lds_bytes, c->stream, c->p, a);
-    else
-        hipLaunchKernelGGL(c->fn, dim3(grid), dim3(c->NT), c->lds_bytes, c->stream, c->p, a);
+    // a profiled launch carries its own start / stop events (hipExtLaunchKernel): they take the kernel's
+    // begin and end timestamps, as rocprofv3's kernel trace does -- a pair of hipEventRecord around the launch
+    // would also span the dispatch of the kernel and of the second marker (4-8 us per launch here)
+    if (use_generic) {
+        if (e0) hipExtLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, e0, e1, 0, c->p, a,
+                                      c->dScratch, c->scratch_stride);
+        else hipLaunchKernelGGL(k_resample_generic, dim3(grid), dim3(256), 0, c->stream, c->p, a, c->dScratch,
+                                c->scratch_stride);
+    } else {
+        const resample_fn fn = emit ? c->fn_emit : c->fn;
+        const int nt = emit ? c->NT_emit : c->NT;
+        if (e0) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(nt), (uint32_t)c->lds_bytes, c->stream, e0, e1, 0, c->p, a);
+        else hipLaunchKernelGGL(fn, dim3(grid), dim3(nt), c->lds_bytes, c->stream, c->p, a);
+    }
     HIP_TRY(hipGetLastError());
-    if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
     if (emit) {  // before the next k_count_tables rewrites the image's cluster sizes
         const int64_t nb = (hi - lo + 255) / 256;
         hipLaunchKernelGGL(k_probs_finish, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, c->stream, c->p,

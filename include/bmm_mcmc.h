@@ -266,10 +266,10 @@ int bmm_chain_stream(bmm_chain* c, void** hip_stream);
 int bmm_chain_shard_deltas(bmm_chain* c, void** dNk, void** dS);
 int bmm_chain_shard_finish(bmm_chain* c);
 
-/* HIP-event timing of the z-resample kernel on the chain's own stream: turn on, run
- * sweeps, sync, read total milliseconds and launch count since it was turned on.
+/* HIP-event timing of the z-resample kernel on the chain's own stream (start / stop events attached to
+ * the launches): turn on, run sweeps, sync, read total milliseconds and launch count since it was turned on.
  * every = 0 off, 1 every sweep, n the launches of every n-th sweep only (an event pair costs
- * about 3 us of stream time per launch, which a sampled measurement keeps out of the total) */
+ * a few us of stream time per launch, which a sampled measurement keeps out of the total) */
 int bmm_chain_profile(bmm_chain* c, int every);
 int bmm_chain_profile_read(bmm_chain* c, double* resample_ms, int64_t* resample_launches);
 /* batch size in effect */
