@@ -539,7 +539,7 @@ int launch_reduce_deltas(bmm_chain* c) {
 }
 
 int launch_count_tables(bmm_chain* c) {
-    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(320), 0, c->stream, c->p, c->dNk, c->dS,
+    hipLaunchKernelGGL(k_count_tables, dim3(c->p.KT), dim3(kCountTablesThreads), 0, c->stream, c->p, c->dNk, c->dS,
                        c->dDNk, c->dDS, c->dAlpha, c->dTab);
     HIP_TRY(hipGetLastError());
     return BMM_OK;

@@ -162,21 +162,25 @@ __device__ __forceinline__ void write_group_tables(int W, const double* e1, cons
     else write_group_tables_w<kGroupWm>(e1, e0, pc, g0, gc, KT, k, c, T);
 }
 
-__global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
-                                                      int32_t* __restrict__ S,
-                                                      int32_t* __restrict__ dNk,
-                                                      int32_t* __restrict__ dS,
-                                                      const double* __restrict__ alpha_ptr,
-                                                      double* __restrict__ tab) {
-    __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP], cst[2];
+constexpr int kCountTablesThreads = 576;
+__global__ __launch_bounds__(kCountTablesThreads) void k_count_tables(ChainParams p, int32_t* __restrict__ Nk,
+                                                                     int32_t* __restrict__ S,
+                                                                     int32_t* __restrict__ dNk,
+                                                                     int32_t* __restrict__ dS,
+                                                                     const double* __restrict__ alpha_ptr,
+                                                                     double* __restrict__ tab) {
+    __shared__ double e1[kMaxP], e0[kMaxP], m1[kMaxP], m0[kMaxP], cst[4];  // cst: Cp, Cm, the two denominators
     const int k = blockIdx.x;
     const TableLayout L = layout_of(p, true);
     const int P = p.P;
     const bool is_label = k < p.K;
-    // 320 threads: the first 128 compute the full-statistics terms of feature d, the next 128 its
-    // "minus self" terms (two logs each instead of four in sequence), the fifth wave the per-cluster
-    // constants (three more logs) beside them
-    const int half = threadIdx.x >> 7, dl = threadIdx.x < 256 ? (threadIdx.x & 127) : kMaxP;
+    // 576 threads, ONE log_ each on the critical path (a log_ is about 150 dependent instructions).  Waves
+    // 0-7: role r = thread / 128 -- the term of feature d for x = 1 and for x = 0 against the full
+    // statistics (r = 0, 1) and with the scored observation removed (r = 2, 3).  Wave 8: the cluster's
+    // constants, one log per lane (the two denominators, the prior terms), combined by its lane 0 with the
+    // operations of the serial form; the term threads subtract the denominators after a barrier.
+    const int role = threadIdx.x >> 7;
+    const int dl = role < 4 ? (threadIdx.x & 127) : kMaxP;
     // every load this workgroup depends on goes out first, in one round trip: the cluster size
     // (read by every thread: a broadcast, no LDS hand-over), the concentration, the first chunk of counts
     int32_t n_old = 0, n_dl = 0, s_old = 0, s_dl = 0;
@@ -186,54 +190,65 @@ __global__ __launch_bounds__(320) void k_count_tables(ChainParams p, int32_t* __
     const double alpha = *alpha_ptr;
     const int64_t n = (int64_t)n_old + n_dl;
     const double bg = p.beta + p.gamma;
-    const double den_p = n > 0 ? log_(bg + (double)n) : 0.0;
-    const double den_m = n > 1 ? log_(bg + (double)(n - 1)) : 0.0;
-    if (threadIdx.x == 256) {
-        double cp = neg_inf(), cm = neg_inf();
-        const double ldN = log_((double)(p.Ntot - 1) + alpha);
-        if (is_label) {
-            if (p.mode == MODE_COLLAPSED) {
-                const double ak = div_(alpha, (double)p.K);
-                if (n > 0) cp = log_((double)n + ak) - ldN;
-                if (n > 1) cm = log_((double)(n - 1) + ak) - ldN;
-            } else {
-                if (n > 0) cp = log_((double)n) - ldN;
-                if (n > 1) cm = log_((double)(n - 1)) - ldN;
-            }
-        } else if (p.mode == MODE_DP && k == p.K) {
-            cp = (log_(alpha) - ldN) + (double)P * (log_(p.beta) - log_(bg));
+    if (role == 4) {
+        const int lane = threadIdx.x & 63;
+        const bool dp_new = p.mode == MODE_DP && k == p.K;
+        const double ak = p.mode == MODE_COLLAPSED ? div_(alpha, (double)p.K) : 0.0;
+        double arg = 1.0;
+        bool need = false;
+        switch (lane) {
+            case 0: arg = bg + (double)n; need = is_label && n > 0; break;                 // log(beta+gamma+n)
+            case 1: arg = bg + (double)(n - 1); need = is_label && n > 1; break;           // ... with one removed
+            case 2: arg = (double)n + ak; need = is_label && n > 0; break;                 // log(n + alpha/K), log n
+            case 3: arg = (double)(n - 1) + ak; need = is_label && n > 1; break;
+            case 4: arg = (double)(p.Ntot - 1) + alpha; need = true; break;                // log(N - 1 + alpha)
+            case 5: arg = alpha; need = dp_new; break;
+            case 6: arg = p.beta; need = dp_new; break;
+            case 7: arg = bg; need = dp_new; break;
+            default: break;
         }
-        tab[L.cp() + k] = cp;
-        tab[L.cm() + k] = cm;
-        cst[0] = cp; cst[1] = cm;  // read after the first barrier below
-        reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
+        const double v = need ? log_(arg) : 0.0;
+        const double den_p = __shfl(v, 0), den_m = __shfl(v, 1), ln = __shfl(v, 2), lm = __shfl(v, 3);
+        const double ldN = __shfl(v, 4), la = __shfl(v, 5), lb = __shfl(v, 6), lbg = __shfl(v, 7);
+        if (lane == 0) {
+            double cp = neg_inf(), cm = neg_inf();
+            if (is_label) {
+                if (n > 0) cp = ln - ldN;
+                if (n > 1) cm = lm - ldN;
+            } else if (dp_new) {
+                cp = (la - ldN) + (double)P * (lb - lbg);
+            }
+            tab[L.cp() + k] = cp;
+            tab[L.cm() + k] = cm;
+            cst[0] = cp; cst[1] = cm; cst[2] = den_p; cst[3] = den_m;  // read after the first barrier below
+            reinterpret_cast<int32_t*>(tab + L.nk())[k] = (int32_t)n;
+        }
     }
     for (int c0 = 0; c0 < P; c0 += kChunkP) {  // kChunkP features (whole groups) at a time
         const int pc = P - c0 < kChunkP ? P - c0 : kChunkP;
         int32_t s = 0;
+        double raw = 0.0;
+        bool have = false;
+        if (dl < pc && is_label) {
+            const int d = c0 + dl;
+            s = c0 == 0 ? s_old + s_dl : S[(size_t)k * P + d] + delta_take(dS, (size_t)k * P + d, KP);
+            // term_x1 / term_x0 of bmm_spec.h, the denominator subtracted below
+            if (role == 0) { have = n > 0; raw = have ? log_(p.beta + (double)s) : 0.0; }
+            else if (role == 1) { have = n > 0; raw = have ? log_((p.gamma + (double)n) - (double)s) : 0.0; }
+            else if (role == 2) { have = n > 1 && s >= 1; raw = have ? log_(p.beta + (double)((int64_t)s - 1)) : 0.0; }
+            else { have = n > 1 && s <= n - 1; raw = have ? log_((p.gamma + (double)(n - 1)) - (double)s) : 0.0; }
+        }
+        __syncthreads();  // the constants are in place; every role has read S + dS before either is rewritten
         if (dl < pc) {
-            const int d = c0 + dl;
-            double t1 = 0.0, t0 = 0.0;
-            if (is_label) {
-                s = c0 == 0 ? s_old + s_dl : S[(size_t)k * P + d] + delta_take(dS, (size_t)k * P + d, KP);
-                if (half == 0) {
-                    if (n > 0) {
-                        t1 = term_x1(p.beta, s, den_p);
-                        t0 = term_x0(p.gamma, n, s, den_p);
-                    }
-                } else if (n > 1) {
-                    t1 = s >= 1 ? term_x1(p.beta, (int64_t)s - 1, den_m) : 0.0;
-                    t0 = s <= n - 1 ? term_x0(p.gamma, n - 1, s, den_m) : 0.0;
-                }
+            const double t = have ? raw - cst[role < 2 ? 2 : 3] : 0.0;
+            (role == 0 ? e1 : role == 1 ? e0 : role == 2 ? m1 : m0)[dl] = t;
+            if (role == 0 && is_label) {
+                const int d = c0 + dl;
+                S[(size_t)k * P + d] = s;
+                delta_clear(dS, (size_t)k * P + d, KP);
             }
-            if (half == 0) { e1[dl] = t1; e0[dl] = t0; } else { m1[dl] = t1; m0[dl] = t0; }
         }
-        __syncthreads();  // both halves have read S + dS before either is rewritten
-        if (half == 0 && dl < pc && is_label) {
-            const int d = c0 + dl;
-            S[(size_t)k * P + d] = s;
-            delta_clear(dS, (size_t)k * P + d, KP);
-        }
+        __syncthreads();
         write_group_tables(p.W, e1, e0, pc, c0, p.KT, k, cst[0], tab + L.tp());
         write_group_tables(kGroupWm, m1, m0, pc, c0, p.KT, k, cst[1], tab + L.tm());
         __syncthreads();
