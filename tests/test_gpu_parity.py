@@ -420,6 +420,15 @@ def test_shapes_whose_tables_need_the_narrower_groups(oracle):
     for i in (0, 1, 777, N - 1):
         _, norm = oracle.collapsed_cond(X, zb, i, K, 1.5, 0.5, 0.5, spec=True)
         assert np.array_equal(probs[i], norm)
+    labels = {}
+    for layout in ("bits", "int32"):                         # the int32 kernels at the narrower width too
+        with bm.Chain("collapsed", N, P, K, batch=900, seed=6, x_layout=layout) as ch:
+            ch.set_data(X)
+            ch.set_initial_labels(z0)
+            ch.sweeps(3)
+            labels[layout] = ch.labels()
+    assert np.array_equal(labels["bits"], labels["int32"])
+    assert np.array_equal(labels["bits"], oracle.collapsed(X, z0, 4, K, 0.0, 0.5, 0.5, 1, 1, 3, seed=6, batch=900)["z"][0])
     N, P, K = 3000, 64, 64
     X, _, _, _ = synth(N, P, 6, 53)
     pi0, th0 = _sb_init(K, P, 2)
