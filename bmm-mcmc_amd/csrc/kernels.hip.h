@@ -721,12 +721,20 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #ifndef BMM_LOOKUP_PRIO
 #define BMM_LOOKUP_PRIO 2
 #endif
+
 // EMIT: the launch also writes the draw's weights and their total (a.wts, a.wtot) for the probability
 // hand-off to the host's relabelling; a twin instantiation, so that the plain kernel carries no branch.
 // GW: features per lookup group of the tables (the shape's width, ChainParams::W).
 template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false, int GW = kGroupW>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
     constexpr int GM = 1 << GW;  // entries per group table
+    // Bit planes, one lane per observation: a wave runs its scoring loop at raised priority.  Scoring is
+    // bound by the CU's LDS pipe, the draw by the SIMD's VALU; with only four waves per SIMD the VALU
+    // starves whenever all four sit in their scoring loops, so a scoring wave gets its few instructions in
+    // ahead of the drawing waves (it stalls on LDS most of the time anyway) and leaves the loop sooner:
+    // C5 +3.5 %, c3 +2.6 % over raising the priority for the issue of the reads only (which was +2 % over
+    // none); the int32 pipeline and the two-lane form lose 1-3 % with it (profiles/r02/README.md).
+    constexpr bool kPrioKernel = BITS && SPLIT == 1;
     static_assert(SPLIT == 1 || (SPLIT == 2 && BITS && MINUS != 2 && KT % 2 == 0), "split form");
     constexpr int SB = BITS ? 32 : STG;  // start bits of the lookup groups one stage scores
     constexpr int KH = KT / SPLIT;      // accumulators per lane
@@ -907,6 +915,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             double acc[KH];
 #pragma unroll
             for (int k = 0; k < KH; ++k) acc[k] = 0.0;
+            if (kPrioKernel) __builtin_amdgcn_s_setprio(BMM_LOOKUP_PRIO);
 #pragma unroll 1
             for (int h = 0; h < nstages; ++h) {
                 if (has_next) {
@@ -930,13 +939,8 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
 #pragma unroll
                     for (int c0 = 0; c0 < KH; c0 += CH) {
                         double tv[CH];
-                        // bit planes, one lane per observation: the reads go out at raised priority, so a
-                        // wave that has reached its lookups gets them into the LDS queue ahead of the other
-                        // waves' adds (+2 % measured; the int32 pipeline and the two-lane form lose 2-4 %)
-                        if (BITS && SPLIT == 1) __builtin_amdgcn_s_setprio(BMM_LOOKUP_PRIO);
 #pragma unroll
                         for (int j = 0; j < CH; ++j) tv[j] = row[(c0 + j) * GM];
-                        if (BITS && SPLIT == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                         for (int j = 0; j < CH; ++j) acc[c0 + j] = acc[c0 + j] + tv[j];
                         if (CH < KH) __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart
@@ -946,6 +950,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
                 if (!BITS && has_next) put_stage<STG>(pack_stage<STG>(P, h, st), h, n0, n1, n2, n3);
                 DIAG({ const unsigned long long n_ = diag_stamp(); d_pack += n_ - d_t; d_t = n_; })
             }
+            if (kPrioKernel) __builtin_amdgcn_s_setprio(0);
             // scores (the constant terms sit in group 0 of the tables); the observation's own
             // cluster is scored without itself
             double m = neg_inf();
