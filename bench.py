@@ -303,7 +303,7 @@ def main():
                        "exponentials -- not by HBM.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, "
                        "profiles/) / launch time measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  lds_frac is "
                        "the same for the LDS reads the scoring cannot avoid against 256 B/clk/CU (the PMC passes "
-                       "show the LDS pipe busy 64 % and the VALU 69 % of a launch: the two limits are co-binding).  "
+                       "show the LDS pipe busy 65 % and the VALU 71 % of a launch: the two limits are co-binding).  "
                        "hbm_frac is SURVEY.md 8d's figure for the bytes this layout streams; the HBM-bound kernel is "
                        "other_workloads.c5_int32")
         return out
