@@ -90,3 +90,27 @@ def test_dp_default_batch_against_the_sequential_scan(oracle):
         seq.append(proportions(want["z"], 30)[:2])
     hip, seq = np.mean(hip, axis=0), np.mean(seq, axis=0)
     assert np.abs(hip - seq).max() <= 2 * bm.TOL_PROPORTIONS + 0.02, (hip, seq)
+
+
+def test_default_batch_on_a_larger_shuffled_mixture(oracle):
+    """the same contract away from the bundled sets: N = 20 000, K = 4, P = 12 (SURVEY 8d's generator, rows
+    shuffled), HIP at the default batch (N/8 = 2500) against the oracle's sequential scan, two seeds --
+    proportions and theta-hat within the stated tolerances of each other and of the generating values"""
+    from util import synth
+    N, P, K = 20000, 12, 4
+    X, _, theta_true, w_true = synth(N, P, K, 77)
+    assert bm.default_batch("collapsed", N) == N // 8
+    hip_p, seq_p, hip_t, seq_t = [], [], [], []
+    for s in (11, 12):
+        z0 = _z0(N, K, s)
+        got = bm.gibbs_collapsed(X, 160, K, burnin=80, seed=s, initial_K=z0)
+        want = oracle.collapsed(X, z0, 160, K, 0.0, 0.5, 0.5, 1, 1, 80, seed=s, batch=1)
+        hip_p.append(proportions(got["z"], K)); seq_p.append(proportions(want["z"], K))
+        hip_t.append(_theta_by_size(got, K)); seq_t.append(_theta_by_size(want, K))
+    hip_p, seq_p = np.mean(hip_p, axis=0), np.mean(seq_p, axis=0)
+    hip_t, seq_t = np.mean(hip_t, axis=0), np.mean(seq_t, axis=0)
+    assert np.abs(hip_p - seq_p).max() <= bm.TOL_PROPORTIONS, (hip_p, seq_p)
+    assert np.abs(hip_t - seq_t).max() <= bm.TOL_THETA, np.abs(hip_t - seq_t).max()
+    assert np.abs(hip_p - np.sort(w_true)[::-1]).max() <= 0.02, hip_p
+    order = np.argsort(-w_true, kind="stable")
+    assert np.abs(hip_t - theta_true[order]).max() <= bm.TOL_THETA, np.abs(hip_t - theta_true[order]).max()
