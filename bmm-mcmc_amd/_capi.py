@@ -25,7 +25,7 @@ SYMBOLS = [
     "bmm_device_count", "bmm_collapsed_run_probs", "bmm_dp_run_probs", "bmm_sb_run_probs", "bmm_full_run_probs",
     "bmm_multi_run", "bmm_multi_selfcheck", "bmm_chains_sweeps", "bmm_chain_share_data", "bmm_chain_planes",
     "bmm_chain_planes_filled", "bmm_chain_shard_resample_async", "bmm_chain_stream",
-    "bmm_chains_broadcast_planes",
+    "bmm_chains_broadcast_planes", "bmm_set_progress", "bmm_last_run_phases", "bmm_host_threads",
 ]
 
 
@@ -83,14 +83,17 @@ def device_count():
 
 
 def as_x(data):
-    """N x P integer matrix in R's layout (column-major int32); values must be 0/1."""
+    """N x P integer matrix in R's layout (column-major int32).  That the values are 0/1 is checked by the
+    library when the matrix is handed over (in the same pass that packs it): a second pass here would cost
+    as much as 100 sweeps at the north-star shape."""
     X = np.asarray(data)
     if X.ndim != 2:
         raise ValueError("data must be a matrix with observations in rows")
     if X.dtype.kind == "f":
         if not np.all(X == np.round(X)):
             raise ValueError("data must be integer valued")
-    X = np.asfortranarray(X, dtype=np.int32)
-    if X.size and (X.min() < 0 or X.max() > 1):
-        raise ValueError("data must be binary (0/1)")
-    return X
+    elif X.dtype.kind not in "iub":
+        raise ValueError("data must be an integer (0/1) matrix")
+    if X.dtype != np.int32 and X.size and (X.min() < 0 or X.max() > 1):
+        raise ValueError("data must be binary (0/1)")  # before a narrowing cast could hide it
+    return np.asfortranarray(X, dtype=np.int32)

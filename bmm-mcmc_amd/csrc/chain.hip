@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen when a run spans devices
 
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -18,7 +19,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -85,6 +89,173 @@ struct ThreadGroup {
     std::vector<std::thread> th;
     ~ThreadGroup() { join(); }
     void join() { for (std::thread& t : th) if (t.joinable()) t.join(); }
+};
+
+// CPUs this process may use for the host-side ends of a run (packing X on its way in, widening the label
+// trace on its way out): the affinity mask, cut to a cgroup CPU quota where there is one (a container that
+// is granted 16 of a host's 256 hardware threads), at most 16 -- memory bandwidth is what those loops need.
+int host_threads() {
+    static const int n = [] {
+        int n = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+        long long quota = -1, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[32] = "";
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // v1
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) != 1) period = 0;
+                fclose(h);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const int c = (int)((quota + period - 1) / period);
+            if (c >= 1 && c < n) n = c;
+        }
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }();
+    return n;
+}
+
+// f(lo, hi) over [0, n) in one contiguous range per thread (whole multiples of `align`), the calling thread
+// taking the first; f must not throw
+template <class F>
+void parallel_ranges(int64_t n, int64_t min_per_thread, int64_t align, F&& f) {
+    int64_t t = host_threads();
+    if (min_per_thread > 0 && n / min_per_thread < t) t = n / min_per_thread;
+    if (t <= 1) { f((int64_t)0, n); return; }
+    int64_t per = (n + t - 1) / t;
+    per = (per + align - 1) / align * align;
+    ThreadGroup tg;
+    tg.th.reserve((size_t)t);
+    for (int64_t lo = per; lo < n; lo += per) {
+        const int64_t hi = lo + per < n ? lo + per : n;
+        tg.th.emplace_back([&f, lo, hi]() { f(lo, hi); });
+    }
+    f((int64_t)0, per < n ? per : n);
+}
+
+// Observations [a, b) of the N x P int32 column-major matrix R hands over, as bit planes: word w of
+// observation i at out[w * ld + (i - a0)] (feature d at bit d % 32 of word d / 32, bits past P zero -- what
+// k_pack_bits writes on the device).  Eight columns at a time into a block of output words that stays in L1:
+// every cell of X is read once, in long contiguous runs, eight independent streams in flight per thread (one
+// stream alone leaves a core at 6.5 GB/s, eight at 10).  Returns the OR of all cells read: the caller rejects
+// the matrix when that has a bit other than bit 0 (data must be 0/1, as k_validate_binary checks).
+uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b, uint32_t* out, int64_t ld, int64_t a0) {
+    constexpr int64_t BL = 4096;
+    constexpr int NS = 8;
+    const int W = (P + 31) / 32;
+    uint32_t seen = 0;
+    for (int64_t r = a; r < b; r += BL) {
+        const int64_t n = b - r < BL ? b - r : BL;
+        for (int w = 0; w < W; ++w) {
+            uint32_t* __restrict const o = out + (int64_t)w * ld + (r - a0);
+            const int d0 = 32 * w, nd = P - d0 < 32 ? P - d0 : 32;
+            const uint32_t* const col = reinterpret_cast<const uint32_t*>(X) + (int64_t)d0 * N + r;
+            int j = 0;
+            for (; j + NS <= nd; j += NS) {
+                const uint32_t* __restrict c[NS];
+                for (int q = 0; q < NS; ++q) c[q] = col + (int64_t)(j + q) * N;
+                for (int64_t t = 0; t < n; ++t) {
+                    uint32_t acc = 0, s = 0;
+                    for (int q = 0; q < NS; ++q) { const uint32_t v = c[q][t]; s |= v; acc |= v << q; }
+                    seen |= s;
+                    o[t] = j == 0 ? acc : (o[t] | (acc << j));
+                }
+            }
+            for (; j < nd; ++j) {
+                const uint32_t* __restrict const c0 = col + (int64_t)j * N;
+                for (int64_t t = 0; t < n; ++t) { const uint32_t v = c0[t]; seen |= v; o[t] = j == 0 ? v : (o[t] | (v << j)); }
+            }
+        }
+    }
+    return seen;
+}
+
+// All of a host matrix packed by the worker threads while the calling thread goes on (a *_run call creates
+// its chain and uploads the starting state meanwhile); the planes land in ordinary host memory: [w][N].
+struct AsyncPack {
+    std::unique_ptr<uint32_t[]> words;
+    std::atomic<uint32_t> seen{0};
+    std::thread th;
+    void start(const int32_t* X, int64_t N, int P) {
+        const int W = (P + 31) / 32;
+        words.reset(new uint32_t[(size_t)W * (size_t)N]);
+        uint32_t* const out = words.get();
+        th = std::thread([this, X, N, P, out]() {
+            parallel_ranges(N, 32768, 64, [&](int64_t lo, int64_t hi) {
+                seen.fetch_or(pack_rows_host(X, N, P, lo, hi, out, N, 0), std::memory_order_relaxed);
+            });
+        });
+    }
+    bool running() const { return th.joinable(); }
+    void join() { if (th.joinable()) th.join(); }
+    ~AsyncPack() { join(); }
+};
+
+// Pinned staging in pieces of 4 MiB that outlive a call: pinning costs about a millisecond per piece, a run
+// needs two on the way in and two on the way out, and an R session calls the samplers again and again.  At
+// most eight idle pieces are kept; the pool itself is never destroyed (no HIP call at process exit).
+constexpr size_t kStageBytes = (size_t)4 << 20;
+struct StagePool {
+    std::mutex m;
+    std::vector<void*> idle;
+    void* get() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!idle.empty()) { void* p = idle.back(); idle.pop_back(); return p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kStageBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void put(void* p) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (idle.size() < 8) { idle.push_back(p); return; }
+        }
+        (void)hipHostFree(p);
+    }
+};
+StagePool& stage_pool() { static StagePool* const pool = new StagePool(); return *pool; }
+struct Stage {  // one piece, back to the pool on every return path
+    void* p = stage_pool().get();
+    ~Stage() { stage_pool().put(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// pinned host staging that is released on every return path
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+struct EventPair {
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~EventPair() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    hipError_t create() {
+        hipError_t r = hipEventCreateWithFlags(&e[0], hipEventDisableTiming);
+        return r == hipSuccess ? hipEventCreateWithFlags(&e[1], hipEventDisableTiming) : r;
+    }
+};
+
+// ---- progress reports and phase times of the *_run entry points (per calling thread)
+struct Progress { bmm_progress_fn fn = nullptr; void* user = nullptr; int every = 0; };
+thread_local Progress g_progress;
+thread_local double g_phase_ms[BMM_RUN_PHASES] = {0, 0, 0, 0, 0, 0};
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int phase) {
+        const auto n = std::chrono::steady_clock::now();
+        g_phase_ms[phase] += std::chrono::duration<double, std::milli>(n - t).count();
+        t = n;
+    }
 };
 
 // accumulator counts the resample kernel is instantiated for
@@ -283,6 +454,9 @@ struct bmm_chain {
     bool xb_borrowed = false;     // this chain took its planes from another one
     bool bits = false;
     int num_cus = 0;
+    // the chain's fixed state is carved out of one allocation (arena), the buffers of a *_run call out of a
+    // second one (run_arena): a malloc / free pair per buffer cost the drop-in call more than a millisecond
+    char *arena = nullptr, *run_arena = nullptr;
     int32_t* dZ[2] = {nullptr, nullptr};
     int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
     double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
@@ -293,10 +467,13 @@ struct bmm_chain {
     int burnin = 0, S = 0;
     int32_t* dTrace = nullptr;  // [S][N], 0-based
     double *dThetaTrace = nullptr, *dAlphaTrace = nullptr, *dPiTrace = nullptr;
+    char* dOutBlk[2] = {nullptr, nullptr};  // staging of the label trace on its way out (trace_out)
+    size_t out_blk_bytes = 0;
 
     int32_t* dNkTrace = nullptr;  // [n][K] cluster sizes per sweep of the current sweeps_counts call
     int nk_trace_base = 0;        // sweep index of its row 0
     unsigned long long* dDiag = nullptr;
+    int* dDbgFlag = nullptr;      // -DBMM_DEBUG_HOOKS: raised by a kernel that meets a label out of range
     int prof = 0;             // > 0: HIP events around the resample launches of every prof-th sweep
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -336,19 +513,16 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
 }
 
 // Default batch: N/8 for the finite sampler, N/16 for the DP sampler (above that every "new" draw of a
-// batch shares one label and spurious clusters open); the stated tolerance against the sequential scan
-// is in include/bmm_mcmc.h, the measurements behind it in DESIGN.md section 2.
-// A pure function of (sampler, N) -- no device, occupancy or layout enters, so a defaulted batch
-// names the same chain everywhere.  Above 3 * 2^18 observations it is rounded up to whole multiples of
-// that: 256 workgroups x 3072 observations, i.e. whole rounds of the chip for 1024-, 768- and
-// 512-thread workgroups alike (a multiple of 2^18 alone leaves the 768-thread kernels of the int32
-// layout with 6.67 chunks per wave: one ragged round in seven).
+// batch shares one label and spurious clusters open) -- exactly, never more: the stated tolerance against
+// the sequential scan (include/bmm_mcmc.h) is held at these ratios (tests/test_gpu_tolerance_fixtures.py).
+// Round 2 rounded the batch up to whole rounds of the chip, which just above the threshold almost doubled
+// it (C5 ran at N/6.4); work is handed out per wave in chunks of 64 observations, so a launch that is not a
+// whole number of rounds costs a fraction of one chunk per wave (C5: 8 launches of 4.8 chunks per wave).
+// A pure function of (sampler, N): no device, occupancy or layout enters, so a defaulted batch names the
+// same chain everywhere.
 int64_t default_batch(int sampler, int64_t N) {
     if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
-    int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
-    const int64_t round = (int64_t)3 << 18;
-    if (b > round) b = (b + round - 1) / round * round;
-    if (b > N) b = N;
+    const int64_t b = sampler == BMM_SAMPLER_DP ? N / 16 : N / 8;
     return b < 1 ? 1 : b;
 }
 
@@ -385,6 +559,21 @@ int32_t* label_row(bmm_chain* c, int j) {
 // hardware queue of its own from the runtime, whatever came before: 14.9-15.7 k in both cases.  It costs
 // about 6 ms more per chain created, and beyond four chains per device the queues start to thrash (8
 // chains: 9.9 k against 12.5 k on shared queues).  mode 0: plain stream; 1: high priority; 2: CU mask.
+// compute units of a device, asked once per process (hipGetDeviceProperties costs a good part of a
+// millisecond, and a drop-in call creates a chain every time)
+int device_cus(int device) {
+    static std::mutex m;
+    static int cus[64];
+    if (device < 0 || device >= 64) return 0;
+    std::lock_guard<std::mutex> g(m);
+    if (cus[device] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        cus[device] = prop.multiProcessorCount;
+    }
+    return cus[device];
+}
+
 int chain_stream_create(bmm_chain* c, bool dedicated) {
     int mode = dedicated ? BMM_STREAM_MODE : 0;
     if (const char* m = dbg_env("BMM_DEBUG_STREAM")) mode = atoi(m);
@@ -397,9 +586,8 @@ int chain_stream_create(bmm_chain* c, bool dedicated) {
     } else if (mode == 2) {
         uint32_t mask[16];
         for (uint32_t& w : mask) w = 0xffffffffu;
-        hipDeviceProp_t prop;
-        e = hipGetDeviceProperties(&prop, c->device);
-        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask);
+        const int cus = device_cus(c->device);
+        e = cus > 0 ? hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask) : hipErrorUnknown;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -424,6 +612,17 @@ int chain_dedicated_queue(bmm_chain* c) {
     return BMM_OK;
 }
 
+// bump allocation out of one device buffer, 256-byte aligned pieces
+struct Carver {
+    char* base;
+    size_t used = 0;
+    template <class T> T* take(size_t n) {
+        const size_t off = (used + 255) & ~(size_t)255;
+        used = off + n * sizeof(T);
+        return base ? reinterpret_cast<T*>(base + off) : nullptr;
+    }
+};
+
 int chain_alloc(bmm_chain* c) {
     const ChainParams& p = c->p;
     HIP_TRY(hipSetDevice(c->device));
@@ -433,31 +632,52 @@ int chain_alloc(bmm_chain* c) {
         int rcs = chain_stream_create(c, false);
         if (rcs) return rcs;
     }
-    const size_t nz = (size_t)p.N * sizeof(int32_t);
-    HIP_TRY(hipMalloc(&c->dZ[0], nz));
-    HIP_TRY(hipMalloc(&c->dZ[1], nz));
-    const size_t ns = (size_t)p.K * p.P * sizeof(int32_t), nn = (size_t)p.K * sizeof(int32_t);
-    HIP_TRY(hipMalloc(&c->dNk, nn));
-    HIP_TRY(hipMalloc(&c->dDNk, nn * kDeltaReps));
-    HIP_TRY(hipMalloc(&c->dS, ns));
-    HIP_TRY(hipMalloc(&c->dDS, ns * kDeltaReps));
-    HIP_TRY(hipMalloc(&c->dAlpha, sizeof(double)));
-    HIP_TRY(hipMalloc(&c->dTab, (size_t)layout_of(c).doubles() * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->dPi, (size_t)p.K * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->dTheta, (size_t)p.K * p.P * sizeof(double)));
-    if (c->generic) HIP_TRY(hipMalloc(&c->dScratch, (size_t)c->scratch_stride * p.Kc * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(c->dNk, 0, nn, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dDNk, 0, nn * kDeltaReps, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dS, 0, ns, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dDS, 0, ns * kDeltaReps, c->stream));
-    HIP_TRY(hipMemsetAsync(c->dTab, 0, (size_t)layout_of(c).doubles() * sizeof(double), c->stream));
-    HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz, c->stream));  // -1 = unassigned
-    HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const size_t nz = (size_t)p.N;
+    const size_t ns = (size_t)p.K * p.P, nn = (size_t)p.K;
+    const size_t ntab = (size_t)layout_of(c).doubles();
+    auto carve = [&](Carver& a) {
+        // the statistics, their delta replicas, the table image and the flags first: zeroed in one go
+        c->dNk = a.take<int32_t>(nn);
+        c->dDNk = a.take<int32_t>(nn * kDeltaReps);
+        c->dS = a.take<int32_t>(ns);
+        c->dDS = a.take<int32_t>(ns * kDeltaReps);
+        c->dTab = a.take<double>(ntab);
 #ifdef BMM_DIAG
-    HIP_TRY(hipMalloc(&c->dDiag, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->dDiag, 0, 16 * sizeof(unsigned long long), c->stream));
+        c->dDiag = a.take<unsigned long long>(16);
 #endif
+#ifdef BMM_DEBUG_HOOKS
+        c->dDbgFlag = a.take<int>(1);
+#endif
+        const size_t zeroed = a.used;
+        c->dAlpha = a.take<double>(1);
+        c->dPi = a.take<double>(nn);
+        c->dTheta = a.take<double>(ns);
+        c->dZ[0] = a.take<int32_t>(nz);
+        c->dZ[1] = a.take<int32_t>(nz);
+        return zeroed;
+    };
+    Carver measure{nullptr};
+    carve(measure);
+    HIP_TRY(hipMalloc(&c->arena, measure.used));
+    Carver real{c->arena};
+    const size_t zeroed = carve(real);
+    if (c->generic) HIP_TRY(hipMalloc(&c->dScratch, (size_t)c->scratch_stride * p.Kc * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->arena, 0, zeroed, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dZ[0], 0xff, nz * sizeof(int32_t), c->stream));  // -1 = unassigned
+    HIP_TRY(hipMemcpyAsync(c->dAlpha, &c->alpha0, sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMM_OK;
+}
+
+// test variant only: after a synchronisation, has a kernel met a label outside its range?
+int dbg_labels_ok(bmm_chain* c) {
+#ifdef BMM_DEBUG_HOOKS
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->dDbgFlag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) return set_err(BMM_E_STATE, "a resample kernel produced or read a label outside [0, K): kernel bug (debug-hooks build check)");
+#else
+    (void)c;
+#endif
     return BMM_OK;
 }
 
@@ -466,6 +686,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     ResampleArgs a{};
     a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
+    a.dbg_flag = c->dDbgFlag; a.dbg_inject = dbg_env("BMM_DEBUG_BADLABEL") != nullptr;
     const bool emit = c->probs_dst != nullptr;
     const bool use_generic = c->generic || (emit && !c->fn_emit);  // the int32 layout has no emitting twin
     const int OT = emit ? c->NT_emit : c->OT, gmax = emit ? c->grid_max_emit : c->grid_max;
@@ -506,15 +727,26 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     if (emit) {  // before the next k_count_tables rewrites the image's cluster sizes
         const int64_t nb = (hi - lo + 255) / 256;
         hipLaunchKernelGGL(k_probs_finish, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, c->stream, c->p,
-                           c->dTab, c->dWts, c->dWtot, lo, hi, c->probs_dst);
+                           c->dTab, c->dWts, c->dWtot, z_in, lo, hi, c->probs_dst);
         HIP_TRY(hipGetLastError());
     }
     return BMM_OK;
 }
 
-// buffers of the probability hand-off, allocated on first use
+// buffers and kernel of the probability hand-off, set up on first use
 int probs_alloc(bmm_chain* c, bool with_matrix) {
     const size_t n = (size_t)c->p.N;
+    if (c->bits && !c->generic && !c->fn_emit) {
+        const int minus = explicit_params(c->p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
+        c->fn_emit = resample_kernel_emit(c->p.KT, minus, c->p.W);
+        c->NT_emit = threads_for(c->p.KT, true);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        int pe = 0;
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pe, reinterpret_cast<const void*>(c->fn_emit), c->NT_emit, c->lds_bytes);
+        if (e != hipSuccess) { c->fn_emit = nullptr; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
+        c->grid_max_emit = (pe < 1 ? 1 : pe) * c->num_cus;
+    }
     if (!c->dWts) HIP_TRY(hipMalloc(&c->dWts, n * c->p.Kc * sizeof(double)));
     if (!c->dWtot) HIP_TRY(hipMalloc(&c->dWtot, n * sizeof(double)));
     if (with_matrix && !c->dProbs) HIP_TRY(hipMalloc(&c->dProbs, n * c->p.K * sizeof(double)));
@@ -616,16 +848,7 @@ int pick_kernel(bmm_chain* c) {
         }
     }
     hipError_t e = hipSetDevice(c->device);
-    c->fn_emit = nullptr;
-    if (e == hipSuccess && c->bits) {
-        c->fn_emit = resample_kernel_emit(p.KT, minus, p.W);
-        c->NT_emit = threads_for(p.KT, true);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-        int pe = 0;
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pe, reinterpret_cast<const void*>(c->fn_emit), c->NT_emit, c->lds_bytes);
-        c->grid_max_emit = (pe < 1 ? 1 : pe) * c->num_cus;
-    }
+    c->fn_emit = nullptr;  // the weight-emitting twin is set up when a hand-off first asks for it (probs_alloc)
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     int per_cu = 0;
@@ -702,6 +925,19 @@ int bmm_spec_group_width_for(int sampler, int K, int P) {
 }
 int64_t bmm_default_batch(int sampler, int64_t N) { return default_batch(sampler, N); }
 
+int bmm_set_progress(bmm_progress_fn fn, void* user, int every) {
+    g_progress.fn = every > 0 ? fn : nullptr;
+    g_progress.user = user;
+    g_progress.every = fn && every > 0 ? every : 0;
+    return BMM_OK;
+}
+int bmm_last_run_phases(double* ms) {
+    if (!ms) return set_err(BMM_E_ARG, "null argument");
+    for (int q = 0; q < BMM_RUN_PHASES; ++q) ms[q] = g_phase_ms[q];
+    return BMM_OK;
+}
+int bmm_host_threads(void) { return host_threads(); }
+
 int bmm_device_count(int* n) {
     int k = 0;
     hipError_t e = hipGetDeviceCount(&k);
@@ -745,8 +981,8 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         delete c;
         return set_err(BMM_E_UNSUPPORTED, "%d categories exceed the %d this build supports", p.Kc, kMaxCatsAny);
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
+    const int cus = device_cus(device);
+    if (cus <= 0) { delete c; return set_err(BMM_E_HIP, "hipGetDeviceProperties failed"); }
     const size_t lds_max = kLdsMax;
     const size_t hist_bytes = hist_bytes_of(K, P);
     c->bits = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
@@ -775,7 +1011,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
         c->scratch_stride = threads;
         c->grid_max = (int)(threads / 256);
     } else {
-        c->num_cus = prop.multiProcessorCount;
+        c->num_cus = cus;
         rc = pick_kernel(c);
         if (rc) { delete c; return rc; }
     }
@@ -801,7 +1037,6 @@ void bmm_chain_destroy(bmm_chain* c) {
         if (hipMemcpy(d, c->dDiag, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && d[5])
             fprintf(stderr, "[bmm diag launch] ticks per wave and launch: table staging %.0f, tile loop %.0f, waiting for the workgroup %.0f, flush %.0f\n",
                     d[8] / (double)d[5], d[9] / (double)d[5], d[10] / (double)d[5], d[11] / (double)d[5]);
-        (void)hipFree(c->dDiag);
     }
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -809,9 +1044,7 @@ void bmm_chain_destroy(bmm_chain* c) {
         (void)hipFree(c->planes->d);
         delete c->planes;
     }
-    void* bufs[] = {c->dX_owned, c->dZ[0], c->dZ[1], c->dNk, c->dS, c->dDNk,
-                    c->dDS, c->dAlpha, c->dTab, c->dPi, c->dTheta, c->dTrace, c->dThetaTrace, c->dAlphaTrace,
-                    c->dPiTrace, c->dScratch, c->dProbs, c->dWts, c->dWtot};
+    void* bufs[] = {c->dX_owned, c->arena, c->run_arena, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -860,32 +1093,49 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
         c->have_data = true;
         return BMM_OK;
     }
-    // bit planes: the int32 matrix passes through a staging buffer in slabs of rows (<= 256 MiB) and
-    // never exists whole on the device -- 16 bytes per observation stay instead of 4 P
-    const int W = (P + 31) / 32;
-    if (!c->dXb) { int rcp = planes_alloc(c, (size_t)W * N); if (rcp) return rcp; }
-    int64_t slab = ((int64_t)256 << 20) / ((int64_t)P * 4);
-    slab = slab / 4 * 4;
-    if (slab < 4) slab = 4;
-    if (slab > N) slab = N;
-    DevBuf stagebuf;
-    HIP_TRY(stagebuf.alloc((size_t)slab * P * sizeof(int32_t)));
-    int32_t* const stage = stagebuf.as<int32_t>();
-    int rc = BMM_OK;
-    for (int64_t i0 = 0; i0 < N && rc == BMM_OK; i0 += slab) {
-        const int64_t rows = N - i0 < slab ? N - i0 : slab;
-        hipError_t e = hipMemcpy2DAsync(stage, (size_t)rows * 4, X + i0, (size_t)N * 4, (size_t)rows * 4, (size_t)P,
-                                        hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { rc = set_err(BMM_E_HIP, "uploading X failed: %s", hipGetErrorString(e)); break; }
-        rc = validate_binary(c, stage, rows * P);  // synchronises the stream
-        if (rc == BMM_OK) rc = pack_rows(c, stage, rows, rows, i0);
-        if (rc == BMM_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(BMM_E_HIP, "packing X failed");
-    }
-    if (rc) return rc;
-    if (c->dX_owned) { (void)hipFree(c->dX_owned); c->dX_owned = nullptr; }
-    c->dX = nullptr;
-    c->have_data = true;
-    return BMM_OK;
+    // Bit planes from a host matrix: the host's own cores validate and pack it, slab by slab, into pinned
+    // staging, and only the planes cross PCIe -- 4 * ceil(P/32) bytes per observation instead of 4 * P (8 MB
+    // instead of 200 MB at N = 1e6, P = 50; a pageable 200 MB upload alone took 13.5 ms there, a third of
+    // a 220-sweep run).  Slab s + 1 is packed while slab s is on its way.  Same planes, bit for bit, as
+    // k_pack_bits makes from a matrix already on the device (tests/test_gpu_fullsize.py holds the two
+    // hand-overs to the same chain).
+    return guarded([&]() -> int {
+        const int W = (P + 31) / 32;
+        if (!c->dXb) { int rcp = planes_alloc(c, (size_t)W * N); if (rcp) return rcp; }
+        int64_t slab = (int64_t)(kStageBytes / ((size_t)W * 4));  // one staging piece of packed words per slab
+        slab = slab / 4096 * 4096;
+        if (slab < 4096) slab = 4096;
+        if (slab > N) slab = N;
+        Stage pooled[2];
+        PinnedBuf own[2];
+        uint32_t* pin[2] = {pooled[0].as<uint32_t>(), pooled[1].as<uint32_t>()};
+        if ((size_t)slab * W * 4 > kStageBytes || !pin[0] || !pin[1])  // more than 256 words per observation
+            for (int q = 0; q < 2; ++q) { HIP_TRY(own[q].alloc((size_t)slab * W * 4)); pin[q] = own[q].as<uint32_t>(); }
+        EventPair done;
+        HIP_TRY(done.create());
+        int64_t s = 0;
+        for (int64_t i0 = 0; i0 < N; i0 += slab, ++s) {
+            const int64_t rows = N - i0 < slab ? N - i0 : slab;
+            uint32_t* const buf = pin[s & 1];
+            if (s >= 2) HIP_TRY(hipEventSynchronize(done.e[s & 1]));  // its previous copy has left the buffer
+            std::atomic<uint32_t> seen{0};
+            parallel_ranges(rows, 32768, 64, [&](int64_t lo, int64_t hi) {
+                seen.fetch_or(pack_rows_host(X, N, P, i0 + lo, i0 + hi, buf, slab, i0), std::memory_order_relaxed);
+            });
+            if (seen.load() & ~1u) {
+                (void)hipStreamSynchronize(c->stream);
+                return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
+            }
+            HIP_TRY(hipMemcpy2DAsync(c->dXb + i0, (size_t)N * 4, buf, (size_t)slab * 4, (size_t)rows * 4, (size_t)W,
+                                     hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipEventRecord(done.e[s & 1], c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the staging buffers go out of scope
+        if (c->dX_owned) { (void)hipFree(c->dX_owned); c->dX_owned = nullptr; }
+        c->dX = nullptr;
+        c->have_data = true;
+        return BMM_OK;
+    });
 }
 
 int bmm_chain_set_data_device(bmm_chain* c, const void* dX) {
@@ -965,21 +1215,27 @@ int bmm_chain_planes_filled(bmm_chain* c) {
 }
 
 int bmm_chain_set_initial_labels(bmm_chain* c, const int32_t* z1) {
-    return guarded([&]() -> int {
-        if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
-        if (c->p.mode != MODE_COLLAPSED) return set_err(BMM_E_STATE, "only the finite collapsed sampler takes initial labels");
-        if (c->started) return set_err(BMM_E_STATE, "chain already started");
-        std::vector<int32_t> z0((size_t)c->p.N);
-        for (int64_t i = 0; i < c->p.N; ++i) {
-            if (z1[i] < 1 || z1[i] > c->p.K) return set_err(BMM_E_ARG, "initialK[%lld] = %d outside 1..%d", (long long)i, z1[i], c->p.K);
-            z0[(size_t)i] = z1[i] - 1;
-        }
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMemcpyAsync(c->dZ[0], z0.data(), z0.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->have_init = true;
-        return BMM_OK;
-    });
+    if (!c || !z1) return set_err(BMM_E_ARG, "null argument");
+    if (c->p.mode != MODE_COLLAPSED) return set_err(BMM_E_STATE, "only the finite collapsed sampler takes initial labels");
+    if (c->started) return set_err(BMM_E_STATE, "chain already started");
+    // uploaded as R holds them (1-based), checked and shifted on the device: no host pass over N labels
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t N = c->p.N;
+    DevBuf badbuf;
+    HIP_TRY(badbuf.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(badbuf.p, 0xff, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dZ[1], z1, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const int64_t nb = (N + 255) / 256;
+    hipLaunchKernelGGL(k_labels_from_r, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, c->stream, c->dZ[1], N,
+                       c->p.K, c->dZ[0], badbuf.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, badbuf.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bad != ~0ull)
+        return set_err(BMM_E_ARG, "initialK[%lld] = %d outside 1..%d", (long long)bad, z1[bad], c->p.K);
+    c->have_init = true;
+    return BMM_OK;
 }
 
 int bmm_chain_set_initial_params(bmm_chain* c, const double* pi, const double* theta) {
@@ -1115,7 +1371,7 @@ int bmm_chain_sync(bmm_chain* c) {
         c->prof_n++;
     }
     c->ev_used = 0;
-    return BMM_OK;
+    return dbg_labels_ok(c);
 }
 
 int bmm_chain_sweep_index(const bmm_chain* c) { return c ? c->sweep : -1; }
@@ -1209,17 +1465,37 @@ struct RunIO {
     double *theta_out = nullptr, *alpha_out = nullptr;
 };
 
-// trace buffers of a *_run call (owned by the chain, released with it)
+// Blocks of the outgoing label trace (trace_out): a whole number of observations, at most a staging piece
+size_t out_block_rows(int S, size_t el, int64_t N) {
+    int64_t B = (int64_t)(kStageBytes / ((size_t)S * el));
+    B = B / 32 * 32;
+    if (B < 32) B = 32;
+    return (size_t)(B > N ? N : B);
+}
+
+// buffers of a *_run call: the traces and the two device blocks of the outgoing label trace, one allocation
+// (owned by the chain, released with it)
 int run_prepare(bmm_chain* c, int nsamples, int burnin) {
     const int64_t N = c->p.N;
     const int K = c->p.K, P = c->p.P;
     const int S = nsamples - burnin;
     c->burnin = burnin; c->S = S;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(&c->dTrace, (size_t)S * N * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&c->dThetaTrace, (size_t)S * K * P * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->dAlphaTrace, (size_t)S * sizeof(double)));
-    if (explicit_params(c->p.mode)) HIP_TRY(hipMalloc(&c->dPiTrace, (size_t)S * K * sizeof(double)));
+    const size_t el = K <= 254 ? 1 : 4;
+    c->out_blk_bytes = out_block_rows(S, el, N) * (size_t)S * el;
+    auto carve = [&](Carver& a) {
+        c->dThetaTrace = a.take<double>((size_t)S * K * P);
+        c->dAlphaTrace = a.take<double>((size_t)S);
+        c->dPiTrace = explicit_params(c->p.mode) ? a.take<double>((size_t)S * K) : nullptr;
+        c->dOutBlk[0] = a.take<char>(c->out_blk_bytes);
+        c->dOutBlk[1] = a.take<char>(c->out_blk_bytes);
+        c->dTrace = a.take<int32_t>((size_t)S * N);
+    };
+    Carver measure{nullptr};
+    carve(measure);
+    HIP_TRY(hipMalloc(&c->run_arena, measure.used));
+    Carver real{c->run_arena};
+    carve(real);
     return BMM_OK;
 }
 
@@ -1300,8 +1576,107 @@ int run_sweeps_hooked(bmm_chain* c, int nsamples, const bmm_relabel_hooks* h) {
     return BMM_OK;
 }
 
-// everything after the data are in place: starting state, the sweeps, the traces out
-int run_body(bmm_chain* c, int nsamples, const RunIO& io, const bmm_relabel_hooks* hooks) {
+// The label trace out to the caller's S x N column-major matrix (labels 1-based, NA where unassigned).
+// In that layout the S labels of one observation are contiguous, so a block of observations is a contiguous
+// run of the caller's buffer: the device transposes the [S][N] trace block by block (k_trace_block), each
+// block goes to pinned staging, and the host's cores copy it into place while the next block is on its way --
+// every byte of the (pageable) destination is written once, in order, at the speed of the slower of PCIe
+// and the host's memory.  Up to 254 labels travel as one byte each and are widened by that host copy (a
+// quarter of the PCIe bytes).  Nothing of it can start before the last sweep has finished: each
+// observation's run is complete only then.
+int trace_out(bmm_chain* c, int32_t* z_out, PhaseClock* clock) {
+    const int64_t N = c->p.N;
+    const int S = c->S;
+    const bool narrow = c->p.K <= 254;
+    const size_t el = narrow ? 1 : 4;
+    const int64_t B = (int64_t)out_block_rows(S, el, N);
+    const size_t blk_bytes = (size_t)B * S * el;  // = c->out_blk_bytes
+    // host staging: two pieces of the pool; a trace with so many kept sweeps that 32 observations exceed a
+    // piece gets buffers of its own
+    Stage pooled[2];
+    PinnedBuf own[2];
+    void* hblk[2] = {pooled[0].p, pooled[1].p};
+    if (blk_bytes > kStageBytes || !hblk[0] || !hblk[1])
+        for (int q = 0; q < 2; ++q) { HIP_TRY(own[q].alloc(blk_bytes)); hblk[q] = own[q].p; }
+    EventPair ev;
+    HIP_TRY(ev.create());
+    auto consume = [&](int64_t blk) {
+        const int64_t i0 = blk * B, rows = N - i0 < B ? N - i0 : B;
+        int32_t* const dst = z_out + (size_t)i0 * S;
+        const int64_t n = rows * S;
+        if (narrow) {
+            const uint8_t* const src = static_cast<const uint8_t*>(hblk[blk & 1]);
+            parallel_ranges(n, 1 << 18, 64, [&](int64_t lo, int64_t hi) {
+                for (int64_t q = lo; q < hi; ++q) dst[q] = src[q] ? (int32_t)src[q] : BMM_NA_INTEGER;
+            });
+        } else {
+            const int32_t* const src = static_cast<const int32_t*>(hblk[blk & 1]);
+            parallel_ranges(n, 1 << 18, 64, [&](int64_t lo, int64_t hi) {
+                std::memcpy(dst + lo, src + lo, (size_t)(hi - lo) * sizeof(int32_t));
+            });
+        }
+    };
+    const int64_t nblk = (N + B - 1) / B;
+    for (int64_t blk = 0; blk < nblk; ++blk) {
+        const int64_t i0 = blk * B, rows = N - i0 < B ? N - i0 : B;
+        const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((S + 31) / 32));
+        char* const dblk = c->dOutBlk[blk & 1];
+        // block blk - 2 has been consumed (below) before this iteration started: its staging is free
+        if (narrow) hipLaunchKernelGGL(k_trace_block<uint8_t>, grid, dim3(256), 0, c->stream, c->dTrace, N, S, i0, rows, reinterpret_cast<uint8_t*>(dblk));
+        else hipLaunchKernelGGL(k_trace_block<int32_t>, grid, dim3(256), 0, c->stream, c->dTrace, N, S, i0, rows, reinterpret_cast<int32_t*>(dblk));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hblk[blk & 1], dblk, (size_t)rows * S * el, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(ev.e[blk & 1], c->stream));
+        if (blk >= 1) {
+            HIP_TRY(hipEventSynchronize(ev.e[(blk - 1) & 1]));
+            if (blk == 1 && clock) clock->lap(3);  // the first block has arrived: the sweeps are over
+            consume(blk - 1);
+        }
+    }
+    HIP_TRY(hipEventSynchronize(ev.e[(nblk - 1) & 1]));
+    if (nblk == 1 && clock) clock->lap(3);
+    consume(nblk - 1);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the small traces queued ahead of the blocks
+    return BMM_OK;
+}
+
+// The sweeps of a run that reports its progress (bmm_set_progress): everything is still enqueued ahead of
+// the device, an event after every `every`-th sweep; the calling thread then follows the events and calls
+// the hook as each one is reached.  For the DP sampler the cluster sizes at those sweeps ride along (K
+// int32 into pinned memory) so that the hook gets the number of clusters in use, as the reference prints
+// it (collapsed_gibbs_dp.cpp:99).
+int run_sweeps_reported(bmm_chain* c, int nsamples) {
+    const int every = g_progress.every, K = c->p.K;
+    const int total = nsamples - 1, marks = (total + every - 1) / every;
+    if (marks < 1) return BMM_OK;
+    std::vector<hipEvent_t> evs((size_t)marks, nullptr);
+    struct Free { std::vector<hipEvent_t>& v; ~Free() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } fr{evs};
+    PinnedBuf sizes;
+    const bool dp = c->p.mode == MODE_DP;
+    if (dp) HIP_TRY(sizes.alloc((size_t)marks * K * sizeof(int32_t)));
+    for (int m = 0; m < marks; ++m) {
+        const int n = total - m * every < every ? total - m * every : every;
+        int rc = bmm_chain_sweeps(c, n);
+        if (rc) return rc;
+        if (dp) HIP_TRY(hipMemcpyAsync(sizes.as<int32_t>() + (size_t)m * K, c->dNk, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventCreateWithFlags(&evs[(size_t)m], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(evs[(size_t)m], c->stream));
+    }
+    for (int m = 0; m < marks; ++m) {
+        HIP_TRY(hipEventSynchronize(evs[(size_t)m]));
+        const int done = (m + 1) * every < total ? (m + 1) * every : total;  // sweeps finished: j = 1 .. done
+        int used = -1;
+        if (dp) { used = 0; for (int k = 0; k < K; ++k) used += sizes.as<int32_t>()[(size_t)m * K + k] > 0; }
+        if (g_progress.fn(g_progress.user, done + 1, nsamples, used) != 0) {
+            (void)hipStreamSynchronize(c->stream);
+            return set_err(BMM_E_CALLBACK, "the progress hook stopped the run after sample %d", done + 1);
+        }
+    }
+    return BMM_OK;
+}
+
+// the starting state of a run: initial labels or parameters, and trace row 0 when burnin = 0
+int run_start_state(bmm_chain* c, const RunIO& io) {
     const int sampler = c->p.mode, K = c->p.K, P = c->p.P, S = c->S, burnin = c->burnin;
     const int64_t N = c->p.N;
     HIP_TRY(hipSetDevice(c->device));
@@ -1320,20 +1695,38 @@ int run_body(bmm_chain* c, int nsamples, const RunIO& io, const bmm_relabel_hook
             HIP_TRY(hipMemcpy2D(c->dPiTrace, (size_t)S * sizeof(double), io.pi0, sizeof(double), sizeof(double), K, hipMemcpyHostToDevice));
         if (sampler != BMM_SAMPLER_COLLAPSED) HIP_TRY(hipMemset(c->dTrace, 0xff, (size_t)N * sizeof(int32_t)));
     }
-    rc = hooks ? run_sweeps_hooked(c, nsamples, hooks) : bmm_chain_sweeps(c, nsamples - 1);
+    return BMM_OK;
+}
+
+// the sweeps, then the traces out (data and starting state are in place)
+int run_body(bmm_chain* c, int nsamples, const RunIO& io, const bmm_relabel_hooks* hooks) {
+    const int sampler = c->p.mode, K = c->p.K, P = c->p.P, S = c->S;
+    HIP_TRY(hipSetDevice(c->device));
+    PhaseClock clock;
+    int rc = hooks ? run_sweeps_hooked(c, nsamples, hooks)
+                   : (g_progress.fn && g_progress.every > 0 ? run_sweeps_reported(c, nsamples) : bmm_chain_sweeps(c, nsamples - 1));
     if (rc) return rc;
-    // labels: [S][N] 0-based -> S x N column-major 1-based, on the device, then one copy out
-    DevBuf out;
-    HIP_TRY(out.alloc((size_t)S * N * sizeof(int32_t)));
-    hipLaunchKernelGGL(k_trace_to_r, dim3((unsigned)((N + 31) / 32), (unsigned)((S + 31) / 32)), dim3(256), 0,
-                       c->stream, c->dTrace, N, S, out.as<int32_t>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(io.z_out, out.p, (size_t)S * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    clock.lap(2);
+    // theta, alpha, pi: small, queued behind the sweeps
     HIP_TRY(hipMemcpyAsync(io.theta_out, c->dThetaTrace, (size_t)S * K * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(io.alpha_out, c->dAlphaTrace, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (explicit_params(sampler))
         HIP_TRY(hipMemcpyAsync(io.pi_out, c->dPiTrace, (size_t)S * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = trace_out(c, io.z_out, &clock);
+    if (rc) return rc;
+    clock.lap(4);
+    return dbg_labels_ok(c);
+}
+
+// planes packed on the host (AsyncPack: [w][N] in ordinary memory) into the chain: one upload
+int chain_set_planes_host(bmm_chain* c, const uint32_t* words) {
+    const int W = (c->p.P + 31) / 32;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dXb) { int rcp = planes_alloc(c, (size_t)W * c->p.N); if (rcp) return rcp; }
+    HIP_TRY(hipMemcpyAsync(c->dXb, words, (size_t)W * c->p.N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dX = nullptr;
+    c->have_data = true;
     return BMM_OK;
 }
 
@@ -1352,15 +1745,40 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int
     return guarded([&]() -> int {
         int rc = check_run_args(X, nsamples, burnin, io, sampler);
         if (rc) return rc;
+        for (double& v : g_phase_ms) v = 0.0;
+        PhaseClock clock;
+        // The host's cores start validating and packing X at once (bit planes, the default layout) while this
+        // thread creates the chain, allocates the run's buffers and uploads the starting state: the two take
+        // about as long at the north-star shape, and only the planes -- 4 * ceil(P/32) bytes per observation
+        // instead of 4 * P -- then cross PCIe.
+        AsyncPack pack;
+        const bool host_pack = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
+        if (host_pack) pack.start(X, N, P);
         bmm_chain* c = nullptr;
         rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
         if (rc) return rc;
-        struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
-        rc = run_prepare(c, nsamples, burnin);
-        if (rc) return rc;
-        rc = bmm_chain_set_data_host(c, X);
-        if (rc) return rc;
-        return run_body(c, nsamples, io, hooks);
+        {
+            struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
+            rc = run_prepare(c, nsamples, burnin);
+            if (rc == BMM_OK) rc = run_start_state(c, io);
+            if (rc) return rc;
+            clock.lap(1);
+            if (host_pack && c->bits) {
+                pack.join();
+                if (pack.seen.load() & ~1u) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
+                rc = chain_set_planes_host(c, pack.words.get());
+                pack.words.reset();
+            } else {
+                pack.join();
+                rc = bmm_chain_set_data_host(c, X);
+            }
+            if (rc) return rc;
+            clock.lap(0);
+            rc = run_body(c, nsamples, io, hooks);
+            clock.t = std::chrono::steady_clock::now();
+        }
+        clock.lap(5);  // releasing the chain
+        return rc;
     });
 }
 
@@ -1569,13 +1987,16 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
         // one host thread per chain; each enqueues on its own stream, so chains on one device overlap
         std::vector<int> status((size_t)n_chains, BMM_OK);
         std::vector<std::string> msg((size_t)n_chains);
-        std::vector<std::thread> th;
-        for (int c = 0; c < n_chains; ++c)
-            th.emplace_back([&, c]() {
-                status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
-                if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
-            });
-        for (std::thread& t : th) t.join();
+        {
+            ThreadGroup tg;  // joined also when starting a later thread throws: the workers hold references
+            tg.th.reserve((size_t)n_chains);
+            for (int c = 0; c < n_chains; ++c)
+                tg.th.emplace_back([&, c]() {
+                    status[(size_t)c] = run_start_state(chains[(size_t)c], io[(size_t)c]);
+                    if (status[(size_t)c] == BMM_OK) status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
+                    if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                });
+        }
         for (int c = 0; c < n_chains; ++c)
             if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
         return BMM_OK;
@@ -1590,13 +2011,15 @@ int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int sweeps) {
         if (n_chains == 1) return bmm_chain_sweeps(chains[0], sweeps);
         std::vector<int> status((size_t)n_chains, BMM_OK);
         std::vector<std::string> msg((size_t)n_chains);
-        std::vector<std::thread> th;
-        for (int c = 0; c < n_chains; ++c)
-            th.emplace_back([&, c]() {
-                status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
-                if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
-            });
-        for (std::thread& t : th) t.join();
+        {
+            ThreadGroup tg;  // joined also when starting a later thread throws
+            tg.th.reserve((size_t)n_chains);
+            for (int c = 0; c < n_chains; ++c)
+                tg.th.emplace_back([&, c]() {
+                    status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
+                    if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                });
+        }
         for (int c = 0; c < n_chains; ++c)
             if (status[(size_t)c]) return set_err(status[(size_t)c], "chain %d: %s", c, msg[(size_t)c].c_str());
         return BMM_OK;

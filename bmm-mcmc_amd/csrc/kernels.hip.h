@@ -468,7 +468,27 @@ struct ResampleArgs {
     double* wts;           // or null: this sweep also emits the draw's weights, wts[k * N + i] for the Kc
     double* wtot;          //   categories in order, and their total wtot[i] (k_probs_finish normalises)
     unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
+    int* dbg_flag;         // -DBMM_DEBUG_HOOKS builds: set when a kernel meets a label outside its range
+    int dbg_inject;        //   ... and a test's way to make one (BMM_DEBUG_BADLABEL)
 };
+
+// The test variant of the library (-DBMM_DEBUG_HOOKS) checks every label a resample kernel is about to count
+// with: 0 <= new < K, -1 <= old < K.  The LDS histogram is indexed by label without a bound, so a wrong
+// experimental kernel would otherwise scribble over LDS (round 2 lost a GPU call to exactly that).  A bad
+// label raises the chain's flag -- the host turns it into BMM_E_STATE at the next synchronisation -- and the
+// observation is left unassigned and uncounted.  The product build carries none of this.
+#ifdef BMM_DEBUG_HOOKS
+__device__ __forceinline__ void dbg_check_labels(const ResampleArgs& a, bool valid, bool first, int K, int& zn, int& zo) {
+    if (a.dbg_inject && valid && first) zn = K + 3;
+    if (valid && (zn < 0 || zn >= K || zo < -1 || zo >= K)) {
+        atomicOr(a.dbg_flag, 1);
+        zn = -1; zo = -1;
+    }
+}
+#define BMM_DBG_LABELS(a, valid, first, K, zn, zo) dbg_check_labels(a, valid, first, K, zn, zo)
+#else
+#define BMM_DBG_LABELS(a, valid, first, K, zn, zo)
+#endif
 
 // Where a lane sits in a tile of NT consecutive observations.  Lanes past the end of the
 // batch re-read its last observation (and never write back).
@@ -1009,6 +1029,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
             }
             DIAG({ const unsigned long long n_ = diag_stamp(); d_draw += n_ - d_t; d_t = n_; })
 
+            BMM_DBG_LABELS(a, pos.valid, pos.i == a.lo, K, zn, zo);
             DIAG(d_nmov += __popcll(__ballot(pos.valid && zn >= 0 && zn != zo));)
             count_movers(pos.valid && half == 0 && zn >= 0 && zn != zo, zo, zn, b0, b1, b2, b3, hist, K, P, lane);
             DIAG({ const unsigned long long n_ = diag_stamp(); d_mov += n_ - d_t; d_t = n_; })
@@ -1083,7 +1104,7 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
         }
     }
     for (int64_t i = a.lo + gid; i < a.hi; i += (int64_t)gridDim.x * blockDim.x) {
-        const int zo = a.z_in ? a.z_in[i] : -1;
+        int zo = a.z_in ? a.z_in[i] : -1;
         const int zoc = zo < 0 ? 0 : zo;
         double acc_own = 0.0;
         if (has_minus)
@@ -1138,6 +1159,7 @@ __global__ __launch_bounds__(256) void k_resample_generic(ChainParams p, Resampl
                 zn = best >= 0 ? best : zoc;
             }
         }
+        BMM_DBG_LABELS(a, true, i == a.lo, K, zn, zo);
         a.z_out[i] = zn;
         if (zn >= 0 && zn != zo) {
             int32_t* const rNk = a.dNk + (blockIdx.x % kDeltaReps) * K;
@@ -1170,11 +1192,15 @@ __global__ __launch_bounds__(256) void k_count_labels_generic(ChainParams p, con
 // The allocation probabilities of one batch, normalised and filed by label: the matrix the reference
 // stores for Stephens' relabelling (collapsed_gibbs.cpp:162-172, collapsed_gibbs_dp.cpp:190-200,
 // stickbreaking.cpp:129-139).  wts/wtot are what the resample kernel of this batch emitted;
-// probs is N x K column-major.  The DP's new-cluster mass goes under the label it would open
-// (collapsed_gibbs_dp.cpp:193), read from the table image's cluster sizes of this batch.
+// probs is N x K column-major.  The DP's new-cluster mass goes under the label a new cluster would take
+// for THIS observation (choices(K) = unused_clusters.top(), collapsed_gibbs_dp.cpp:169-170,193): the
+// smallest free label of the batch (from the table image's cluster sizes) -- or the observation's own
+// label when it sat alone in its cluster and that label is smaller, because removing it (:113-128) has
+// just returned that label to the heap.  The draw itself (k_resample) opens the same label.
 __global__ __launch_bounds__(256) void k_probs_finish(ChainParams p, const double* __restrict__ tab,
                                                       const double* __restrict__ wts,
-                                                      const double* __restrict__ wtot, int64_t lo, int64_t hi,
+                                                      const double* __restrict__ wtot,
+                                                      const int32_t* __restrict__ z_in, int64_t lo, int64_t hi,
                                                       double* __restrict__ probs) {
     const TableLayout L = layout_of(p, !explicit_params(p.mode));
     const int32_t* const NkT = reinterpret_cast<const int32_t*>(tab + L.nk());
@@ -1184,33 +1210,54 @@ __global__ __launch_bounds__(256) void k_probs_finish(ChainParams p, const doubl
             if (NkT[k] <= 0) new_label = k;
     for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
         const double tot = wtot[i];
+        int own_new = new_label;
+        if (p.mode == MODE_DP && z_in) {
+            const int zo = z_in[i];
+            if (zo >= 0 && NkT[zo] == 1 && (new_label < 0 || zo < new_label)) own_new = zo;
+        }
         for (int k = 0; k < p.Kc; ++k) {
-            const int lbl = k < p.K ? k : new_label;
+            const int lbl = k < p.K ? k : own_new;  // in label order: the new-cluster mass lands last
             if (lbl >= 0) probs[i + (int64_t)lbl * p.N] = div_(wts[(int64_t)k * p.N + i], tot);
         }
     }
 }
 
-// S x N column-major 1-based output from the [S][N] 0-based device trace (tiled transpose)
-__global__ __launch_bounds__(256) void k_trace_to_r(const int32_t* __restrict__ trace, int64_t N, int S,
-                                                    int32_t* __restrict__ out) {
+// The label trace on its way out: observations [i0, i0 + rows) of the [S][N] 0-based device trace as the
+// rows x S block of R's S x N column-major matrix they occupy (out[(i - i0) * S + s]: that block is
+// contiguous in the caller's buffer), labels 1-based.  T = int32_t: unassigned -> NA_integer_;
+// T = uint8_t (at most 254 labels): unassigned -> 0, widened on the host, a quarter of the bytes over PCIe.
+template <typename T>
+__global__ __launch_bounds__(256) void k_trace_block(const int32_t* __restrict__ trace, int64_t N, int S,
+                                                     int64_t i0, int64_t rows, T* __restrict__ out) {
     __shared__ int32_t tile[32][33];
-    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const int64_t b0 = (int64_t)blockIdx.x * 32;  // within the block of observations
     const int s0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         const int s = s0 + r;
-        const int64_t i = i0 + tx;
-        tile[r][tx] = (s < S && i < N) ? trace[(size_t)s * N + i] : 0;
+        const int64_t li = b0 + tx;
+        tile[r][tx] = (s < S && li < rows) ? trace[(size_t)s * N + i0 + li] : 0;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
-        const int64_t i = i0 + r;
+        const int64_t li = b0 + r;
         const int s = s0 + tx;
-        if (s < S && i < N) {
+        if (s < S && li < rows) {
             const int32_t v = tile[tx][r];
-            out[(size_t)i * S + s] = v < 0 ? (int32_t)0x80000000 : v + 1;
+            if (sizeof(T) == 1) out[(size_t)li * S + s] = (T)(v < 0 ? 0 : v + 1);
+            else out[(size_t)li * S + s] = (T)(v < 0 ? (int32_t)0x80000000 : v + 1);
         }
+    }
+}
+
+// initialK as R hands it over (1-based) -> the chain's 0-based label row; bad[0] receives the smallest
+// index whose label lies outside 1..K (or stays at its initial all-ones value)
+__global__ __launch_bounds__(256) void k_labels_from_r(const int32_t* __restrict__ z1, int64_t N, int K,
+                                                       int32_t* __restrict__ z0, unsigned long long* bad) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const int32_t v = z1[i];
+        if (v < 1 || v > K) atomicMin(bad, (unsigned long long)i);
+        z0[i] = v - 1;
     }
 }
 

@@ -81,11 +81,30 @@ const char* bmm_last_error(void);
 int bmm_spec_group_width(void);
 int bmm_spec_group_width_own(void);
 int bmm_spec_group_width_for(int sampler, int K, int P);
-/* library default batch size for N observations (used when batch <= 0): N/8 for the finite
- * sampler, N/16 for the DP sampler (rounded up to a multiple of 3 * 2^18 above that: whole rounds of
- * 256 workgroups of 1024, 768 or 512 threads), N for stick-breaking and full; depends on nothing
- * else.  See DESIGN.md "Batches" */
+/* library default batch size for N observations (used when batch <= 0): floor(N/8) for the finite
+ * sampler, floor(N/16) for the DP sampler (at least 1), N for stick-breaking and full; depends on
+ * nothing else.  See DESIGN.md "Batches" */
 int64_t bmm_default_batch(int sampler, int64_t N);
+
+/* ---- progress of the *_run entry points ---------------------------------------------------
+ * The reference prints "Sample j" at every sweep (src/collapsed_gibbs.cpp:85, stickbreaking.cpp:67; the DP
+ * sampler adds the current number of clusters, collapsed_gibbs_dp.cpp:99).  Here a run is silent unless the
+ * caller installs a hook: after every `every`-th sweep the calling thread calls fn(user, sample, nsamples,
+ * k_used) with sample = the reference's printed index of the sweep just finished (2 .. nsamples), k_used =
+ * the DP sampler's clusters in use after it (-1 for the other samplers).  A non-zero return stops the run
+ * (BMM_E_CALLBACK).  Per calling thread; applies to the single-chain *_run calls made afterwards; fn = NULL
+ * or every <= 0 turns it off.  The sweeps stay enqueued ahead of the device: the hook follows events. */
+typedef int (*bmm_progress_fn)(void* user, int sample, int nsamples, int k_used);
+int bmm_set_progress(bmm_progress_fn fn, void* user, int every);
+/* Wall-clock milliseconds the last single-chain *_run call of this thread spent in: [1] creating the chain,
+ * its buffers and the starting state (the host's other cores validate and pack X meanwhile), [0] what was
+ * left of the packing after that, plus the upload of the planes, [2] enqueueing the sweeps, [3] waiting for
+ * the device to finish them, [4] the label trace on its way out (device transpose, PCIe, host copy into the
+ * caller's matrix), [5] releasing the chain. */
+#define BMM_RUN_PHASES 6
+int bmm_last_run_phases(double* ms /* BMM_RUN_PHASES doubles */);
+/* host threads the two ends of a run use (affinity mask, cgroup CPU quota, at most 16) */
+int bmm_host_threads(void);
 
 /* ---- drop-in entry points --------------------------------------------------------
  * Replaces collapsed_gibbs_cpp (src/collapsed_gibbs.cpp:24-36; .Call symbol

@@ -900,6 +900,7 @@ typedef struct {
     unsigned char* dirty;
     double* score; double* w; double* e;
     double alpha_cur, beta, gamma, a, b;
+    double alpha_consts; /* the alpha Cp/Cm were computed with (NaN: none yet) */
     int sample_alpha;
     uint64_t seed;
     int64_t batch;
@@ -936,6 +937,7 @@ static int chain_init(ochain* c, int sampler, const int32_t* X, int64_t N, int P
     c->e = (double*)malloc(sizeof(double) * 2 * P);
     if (!c->nib || !c->nibm || !c->z || !c->znew || !c->Tp || !c->Tm) return fail("out of memory");
     memset(c->dirty, 1, K);
+    c->alpha_consts = NAN;
     for (int64_t i = 0; i < N; ++i) {
         int k = z0_1based ? z0_1based[i] - 1 : -1;
         if (z0_1based && (k < 0 || k >= K)) return fail("initialK out of range");
@@ -967,24 +969,31 @@ static void chain_batch(ochain* c, int64_t lo, int64_t hi, uint32_t j) {
     const double alpha = c->alpha_cur;
     const double ldN = oracle_log((double)(c->N - 1) + alpha);
     int Kused = 0, new_label = -1;
+    /* tables and constants are functions of (Nk, S, alpha) only: a cluster no observation entered or
+     * left since they were last computed, under the same alpha, keeps them (same values, computed once
+     * -- what makes batch = 1 affordable at N = 10^6) */
+    const int all = !(c->alpha_consts == alpha);
     for (int k = 0; k < K; ++k) {
+        const int64_t n = c->Nk[k];
+        if (c->dirty[k] || all) {
+            if (c->sampler == 0) {
+                c->Cp[k] = n > 0 ? oracle_log((double)n + alpha / (double)K) - ldN : O_NEG_INF;
+                c->Cm[k] = n > 1 ? oracle_log((double)(n - 1) + alpha / (double)K) - ldN : O_NEG_INF;
+            } else {
+                c->Cp[k] = n > 0 ? oracle_log((double)n) - ldN : O_NEG_INF;
+                c->Cm[k] = n > 1 ? oracle_log((double)(n - 1)) - ldN : O_NEG_INF;
+            }
+        }
         if (c->dirty[k]) {
             counts_group_table(c->beta, c->gamma, P, c->gw, c->Nk[k], c->S + (size_t)k * P, 0, c->e, c->e + P, c->Tp + k * tk);
             counts_group_table(c->beta, c->gamma, P, GWM, c->Nk[k], c->S + (size_t)k * P, 1, c->e, c->e + P, c->Tm + k * tkm);
             c->dirty[k] = 0;
         }
-        int64_t n = c->Nk[k];
-        if (c->sampler == 0) {
-            c->Cp[k] = n > 0 ? oracle_log((double)n + alpha / (double)K) - ldN : O_NEG_INF;
-            c->Cm[k] = n > 1 ? oracle_log((double)(n - 1) + alpha / (double)K) - ldN : O_NEG_INF;
-        } else {
-            c->Cp[k] = n > 0 ? oracle_log((double)n) - ldN : O_NEG_INF;
-            c->Cm[k] = n > 1 ? oracle_log((double)(n - 1)) - ldN : O_NEG_INF;
-        }
         if (n > 0) Kused++; else if (new_label < 0) new_label = k;
     }
     const int ncat = c->sampler == 1 ? K + 1 : K;
-    if (c->sampler == 1) c->Cp[K] = dp_new_score(alpha, c->beta, c->gamma, P, ldN);
+    if (c->sampler == 1 && all) c->Cp[K] = dp_new_score(alpha, c->beta, c->gamma, P, ldN);
+    c->alpha_consts = alpha;
     for (int64_t i = lo; i < hi; ++i) {
         const uint8_t* nb = c->nib + (size_t)i * G;
         const uint8_t* nbm = c->nibm + (size_t)i * Gm;
@@ -1034,7 +1043,7 @@ static void chain_sweep(ochain* c, uint32_t j) {
 }
 static void chain_emit(const ochain* c, int s, int S, int32_t* z_out, double* theta_out, double* alpha_out) {
     const int K = c->K, P = c->P;
-    for (int64_t i = 0; i < c->N; ++i) z_out[s + (size_t)i * S] = c->z[i] + 1;
+    if (z_out) for (int64_t i = 0; i < c->N; ++i) z_out[s + (size_t)i * S] = c->z[i] + 1;
     for (int k = 0; k < K; ++k)
         for (int d = 0; d < P; ++d) {
             double v;
@@ -1045,10 +1054,12 @@ static void chain_emit(const ochain* c, int s, int S, int32_t* z_out, double* th
     alpha_out[s] = c->alpha_cur;
 }
 
+/* z_out may be null (no label trace); nk_out, if given, receives the cluster sizes after every kept
+ * sweep (row s = sweep burnin + s, K entries) and z_last the labels (1-based) after the last sweep */
 static int run_counts_chain(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0,
                             int nsamples, int K, double alpha, double beta, double gamma, double a,
                             double b, int burnin, int64_t batch, uint64_t seed, int32_t* z_out,
-                            double* theta_out, double* alpha_out) {
+                            double* theta_out, double* alpha_out, int32_t* nk_out, int32_t* z_last) {
     if (nsamples < 1 || burnin < 0 || burnin > nsamples) return fail("bad nsamples/burnin");
     if (sampler == 1 && beta != gamma)
         return fail("Error: sampler currently not implemented for non-symmetric priors on beta and gamma");
@@ -1056,16 +1067,23 @@ static int run_counts_chain(int sampler, const int32_t* X, int64_t N, int P, con
     if (chain_init(&c, sampler, X, N, P, K, z0, alpha, beta, gamma, a, b, batch, seed)) { chain_free(&c); return 1; }
     int S = nsamples - burnin;
     if (burnin == 0) {
-        for (int64_t i = 0; i < N; ++i) z_out[0 + (size_t)i * S] = z0 ? z0[i] : ORACLE_NA_INT;
+        if (z_out) for (int64_t i = 0; i < N; ++i) z_out[0 + (size_t)i * S] = z0 ? z0[i] : ORACLE_NA_INT;
         for (int q = 0; q < K * P; ++q) theta_out[q] = sampler == 1 ? 0.0 : NAN;
         alpha_out[0] = c.alpha_cur;
+        if (nk_out) memcpy(nk_out, c.Nk, sizeof(int32_t) * K);
     }
     /* alpha_sampled(j) keeps its previous value when alpha is fixed; when sampled the
      * sweep consumes alpha_sampled(j-1) and then draws alpha_sampled(j) */
+    const char* progress = getenv("ORACLE_PROGRESS"); /* fixture generation only: a line per sweep on stderr */
     for (int j = 1; j < nsamples; ++j) {
         chain_sweep(&c, (uint32_t)j);
-        if (j >= burnin) chain_emit(&c, j - burnin, S, z_out, theta_out, alpha_out);
+        if (j >= burnin) {
+            chain_emit(&c, j - burnin, S, z_out, theta_out, alpha_out);
+            if (nk_out) memcpy(nk_out + (size_t)(j - burnin) * K, c.Nk, sizeof(int32_t) * K);
+        }
+        if (progress) fprintf(stderr, "[oracle %s seed %llu] sweep %d / %d\n", progress, (unsigned long long)seed, j, nsamples - 1);
     }
+    if (z_last) for (int64_t i = 0; i < N; ++i) z_last[i] = c.z[i] < 0 ? ORACLE_NA_INT : c.z[i] + 1;
     chain_free(&c);
     return 0;
 }
@@ -1076,13 +1094,25 @@ int oracle_collapsed_run(const int32_t* X, int64_t N, int P, const int32_t* z0, 
                          double* alpha_out) {
     if (!z0) return fail("initialK required");
     return run_counts_chain(0, X, N, P, z0, nsamples, K, alpha, beta, gamma, a, b, burnin, batch, seed,
-                            z_out, theta_out, alpha_out);
+                            z_out, theta_out, alpha_out, NULL, NULL);
 }
 int oracle_dp_run(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta,
                   double gamma, double a, double b, int burnin, int maxK, int64_t batch,
                   uint64_t seed, int32_t* z_out, double* theta_out, double* alpha_out) {
     return run_counts_chain(1, X, N, P, NULL, nsamples, maxK, alpha, beta, gamma, a, b, burnin, batch,
-                            seed, z_out, theta_out, alpha_out);
+                            seed, z_out, theta_out, alpha_out, NULL, NULL);
+}
+/* The same chains without the S x N label trace (which does not fit at N = 10^6 and hundreds of kept
+ * sweeps): cluster sizes per kept sweep, theta-hat, alpha, and the labels after the last sweep.
+ * sampler 0: collapsed (z0 required), 1: dp (z0 ignored, K = maxK).  For tests/golden/make_tolerance_fixtures.py. */
+int oracle_counts_summary(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0, int nsamples,
+                          int K, double alpha, double beta, double gamma, double a, double b, int burnin,
+                          int64_t batch, uint64_t seed, int32_t* nk_out, double* theta_out,
+                          double* alpha_out, int32_t* z_last) {
+    if (sampler != 0 && sampler != 1) return fail("sampler must be 0 (collapsed) or 1 (dp)");
+    if (sampler == 0 && !z0) return fail("initialK required");
+    return run_counts_chain(sampler, X, N, P, sampler == 0 ? z0 : NULL, nsamples, K, alpha, beta, gamma, a, b,
+                            burnin, batch, seed, NULL, theta_out, alpha_out, nk_out, z_last);
 }
 
 /* ------------------------------------------------------------------ CPU baseline timing */

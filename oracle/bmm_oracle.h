@@ -92,6 +92,12 @@ int oracle_dp_literal(const int32_t* X, int64_t N, int P, int nsamples, double a
 int oracle_dp_run(const int32_t* X, int64_t N, int P, int nsamples, double alpha, double beta,
                   double gamma, double a, double b, int burnin, int maxK, int64_t batch,
                   uint64_t seed, int32_t* z_out, double* theta_out, double* alpha_out);
+/* the *_run chains of the two counting samplers without the S x N label trace: cluster sizes per kept
+ * sweep (S x K, row-major by sweep), theta-hat, alpha, labels after the last sweep (1-based) */
+int oracle_counts_summary(int sampler, const int32_t* X, int64_t N, int P, const int32_t* z0, int nsamples,
+                          int K, double alpha, double beta, double gamma, double a, double b, int burnin,
+                          int64_t batch, uint64_t seed, int32_t* nk_out, double* theta_out,
+                          double* alpha_out, int32_t* z_last);
 int oracle_sb_literal(const int32_t* X, int64_t N, int P, const double* pi0, const double* theta0,
                       int nsamples, int maxK, double alpha, double beta, double gamma, double a,
                       double b, int burnin, uint64_t seed, double* pi_out, int32_t* z_out,

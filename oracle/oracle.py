@@ -222,6 +222,26 @@ def dp(X, nsamples, alpha, beta, gamma, a, b, burnin, maxK, seed, batch=1, liter
     return {"alpha": al, "z": z, "theta": th}
 
 
+def counts_summary(sampler, X, z0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed, batch=1):
+    """The collapsed / dp `*_run` chain without the S x N label trace: {"nk": (S, K) cluster sizes after every
+    kept sweep, "theta": K x P x S, "alpha": S x 1, "z_last": labels after the last sweep (1-based)}."""
+    X = _x(X)
+    N, P = X.shape
+    code = {"collapsed": 0, "dp": 1}[sampler]
+    S = nsamples - burnin
+    nk = np.zeros((S, K), dtype=np.int32)
+    th = np.zeros((K, P, S), order="F")
+    al = np.zeros((S, 1), order="F")
+    zl = np.zeros(N, dtype=np.int32)
+    z0p = _vp(np.ascontiguousarray(z0, dtype=np.int32)) if z0 is not None else None
+    rc = lib().oracle_counts_summary(C.c_int(code), _vp(X), C.c_int64(N), C.c_int(P), z0p, C.c_int(nsamples),
+                                     C.c_int(K), C.c_double(alpha), C.c_double(beta), C.c_double(gamma),
+                                     C.c_double(a), C.c_double(b), C.c_int(burnin), C.c_int64(batch),
+                                     C.c_uint64(seed), _vp(nk), _vp(th), _vp(al), _vp(zl))
+    _check(rc)
+    return {"nk": nk, "theta": th, "alpha": al, "z_last": zl}
+
+
 def full(X, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed, literal=False):
     """gibbs_cpp (full_gibbs.cpp): the stick-breaking z-step with a Dirichlet pi draw."""
     return stickbreaking(X, pi0, theta0, nsamples, K, alpha, beta, gamma, a, b, burnin, seed, literal=literal,

@@ -36,9 +36,11 @@ def test_spec_constants_match_oracle(oracle):
 def test_default_batch_policy():
     assert bm.default_batch("stickbreaking", 1000) == 1000
     assert bm.default_batch("collapsed", 100) == 12
-    # a pure function of (sampler, N): N/8 (N/16 dp), in whole multiples of 3 * 2^18 above that
-    assert bm.default_batch("collapsed", 10 ** 7) == 2 * 3 * 2 ** 18
-    assert bm.default_batch("collapsed", 8 * 3 * 2 ** 18) == 3 * 2 ** 18
+    # a pure function of (sampler, N): floor(N/8) (N/16 dp), at least 1 -- never more (round 2 rounded up)
+    assert bm.default_batch("collapsed", 10 ** 7) == 1_250_000
+    for N in (1, 7, 100, 12345, 10 ** 6, 10 ** 7, 8 * 3 * 2 ** 18 + 8, 2 ** 31 + 5):
+        assert bm.default_batch("collapsed", N) == max(1, N // 8)
+        assert bm.default_batch("dp", N) == max(1, N // 16)
     assert bm.default_batch("collapsed", 10 ** 6) == 125000
     assert bm.default_batch("dp", 10 ** 6) == 62500
     assert bm.default_batch("dp", 1600) == 100
@@ -50,8 +52,8 @@ def test_argument_validation_needs_no_gpu():
     X = np.zeros((10, 3), dtype=np.int32)
     with pytest.raises(NotImplementedError, match="relabel"):
         bm.gibbs_collapsed(X, 10, 2, relabel=True)
-    with pytest.raises(ValueError, match="binary"):
-        bm.gibbs_collapsed(X + 2, 10, 2)
+    with pytest.raises(ValueError, match="binary"):      # caught before a narrowing cast could hide it;
+        bm.gibbs_collapsed(X.astype(np.int64) + 2 ** 32, 10, 2)  # int32 input is checked by the library
     with pytest.raises(ValueError, match="burnin"):
         bm.gibbs_dp(X, 10, burnin=10)
 

@@ -1,20 +1,49 @@
 #!/usr/bin/env python3
-"""Where the drop-in call's time goes at the north-star shape (host matrix in, trace out): the same steps
-through the resident-chain API, timed one by one, then gibbs_collapsed itself.  tools/e2e_probe.py"""
-import os, sys, time
+"""Where the drop-in call's time goes (host matrix in, S x N trace out): bmm_collapsed_run through ctypes with the
+library's own phase clock (bmm_last_run_phases), at the north-star shape and at C5.  tools/e2e_probe.py [ns|c5 ...]"""
+import ctypes as C
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+
 import bmm_mcmc_amd as bm
-from bmm_mcmc_amd import synth
-N, P, K = 1_000_000, 50, 20
-X, _, _, _ = synth.host_matrix(N, P, 20, 22)
-z0 = np.random.default_rng(0).integers(1, K + 1, N).astype(np.int32)
-bm.gibbs_collapsed(X[:1000], 3, K, seed=1, initial_K=z0[:1000])
-for rep in range(2):
-    t0 = time.perf_counter(); c = bm.Chain("collapsed", N, P, K, seed=1); t1 = time.perf_counter()
-    c.set_data(X); t2 = time.perf_counter()
-    c.set_initial_labels(z0); t3 = time.perf_counter()
-    c.sweeps(220); c.sync(); t4 = time.perf_counter()
-    z = c.labels(); t5 = time.perf_counter(); c.close()
-    print("create %.1f ms, set_data(host 200 MB) %.1f ms, labels in %.1f ms, 220 sweeps %.1f ms, labels out %.1f ms" % tuple(1e3 * v for v in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)))
-    t0 = time.perf_counter(); out = bm.gibbs_collapsed(X, 220, K, burnin=200, seed=1, initial_K=z0); print("gibbs_collapsed total %.1f ms" % (1e3 * (time.perf_counter() - t0)))
+from bmm_mcmc_amd import _capi, synth
+
+SHAPES = {"ns": (1_000_000, 50, 20, 22, 220, 200), "c5": (10_000_000, 100, 20, 21, 30, 3),
+          "c2": (100_000, 20, 3, 18, 1000, 100)}
+PH = ("create+upload", "start state", "enqueue", "device wait", "trace out", "release")
+
+
+def probe(name, reps=3):
+    N, P, K, dseed, ns, burn = SHAPES[name]
+    X, _, _, _ = synth.host_matrix(N, P, K, dseed)
+    z0 = np.random.default_rng(0).integers(1, K + 1, N).astype(np.int32)
+    S = ns - burn
+    L = _capi.lib()
+    print("%s: N=%d P=%d K=%d nsamples=%d kept=%d, host threads %d" % (name, N, P, K, ns, S, L.bmm_host_threads()))
+    for rep in range(reps):
+        z = np.empty((S, N), dtype=np.int32, order="F")   # as R's allocMatrix: untouched pages
+        th = np.empty((K, P, S), order="F")
+        al = np.empty((S, 1), order="F")
+        t0 = time.perf_counter()
+        rc = L.bmm_collapsed_run(_capi.vp(X), C.c_int64(N), C.c_int(P), _capi.vp(z0), C.c_int(ns), C.c_int(K),
+                                 C.c_double(0), C.c_double(.5), C.c_double(.5), C.c_double(1), C.c_double(1),
+                                 C.c_int(burn), C.c_int64(0), C.c_uint64(1), C.c_int(0), _capi.vp(z), _capi.vp(th), _capi.vp(al))
+        dt = time.perf_counter() - t0
+        _capi.check(rc)
+        ms = (C.c_double * 6)()
+        L.bmm_last_run_phases(ms)
+        print("  rep %d: %.1f ms = %.0f sweeps/s | " % (rep, 1e3 * dt, ns / dt) + ", ".join("%s %.1f" % (n, v) for n, v in zip(PH, ms)))
+        t0 = time.perf_counter()
+        out = bm.gibbs_collapsed(X, ns, K, burnin=burn, seed=1, initial_K=z0)
+        print("         through the Python wrapper: %.1f ms" % (1e3 * (time.perf_counter() - t0)))
+        assert np.array_equal(out["z"], z)
+
+
+if __name__ == "__main__":
+    bm.gibbs_collapsed(np.zeros((1000, 4), np.int32), 3, 2, seed=1)   # context, first-use costs
+    for n in (sys.argv[1:] or ["ns"]):
+        probe(n)
