@@ -14,22 +14,32 @@ RCCL -- the only collective on this path; chains are independent, so scaling is 
 
 Prints ONE JSON line on rank 0.
   roofline       the dominant kernel, k_resample, timed with HIP events on the chain's own stream
-                 inside the timed region.  With X in bit planes (the default layout) the kernel is bound
-                 by fp64 VALU issue, not by HBM: `bound` says so, `achieved`/`peak` are VALU
-                 wave-instructions per second (instructions per 64 observations from the rocprofv3
-                 SQ_INSTS_VALU pass under profiles/, x the observations a launch processes, / the
-                 launch time measured here), and the HBM figure of SURVEY.md section 8d for the
-                 layout actually streamed is kept beside it as hbm_frac.  The kernel that streams
-                 the int32 matrix as R hands it over IS HBM-bound and is measured in the same run
-                 (other_workloads.c5_int32, bound "hbm").
+                 inside the timed region.  `achieved` / `peak` / `frac` are SURVEY.md section 8d's figure:
+                 algorithmic bytes of the layout actually streamed (bit planes: 4*ceil(P/32) + 8 bytes per
+                 observation) per second of kernel time, against the 8 TB/s HBM peak.  With X in bit planes
+                 that fraction is small BY DESIGN (the kernel streams 17x fewer bytes than the int32
+                 layout) and the kernel is bound by what it does per observation on the CU: `bound` says
+                 "valu+lds (compute)", and `valu_util` (VALU wave-instructions issued / issue slots, from
+                 the rocprofv3 SQ_INSTS_VALU pass under profiles/ and the launch time measured here),
+                 `lds_busy`, `lds_conflict_frac` (PMC passes under profiles/) say how busy the two
+                 co-binding pipes are -- utilisation of the instructions this kernel executes, not a
+                 fraction of algorithmic work.
+  roofline_int32 the same workload on the kernel that streams the int32 matrix as R hands it over
+                 (4P + 8 bytes per observation): that one IS HBM-bound (`bound` "hbm") and carries the
+                 north star's ">= 40 % of the HBM roofline on the z-resample kernel" claim; the default
+                 bit-plane kernel is 1.7-1.8x faster in sweeps/s and is what `value` reports.
   cpu_baseline   the oracle's sufficient-statistics chain (same batch semantics) on the host cores
                  of this box: one chain per thread on as many threads as this process may use, up
                  to one socket's cores; on a bounded row sample, scaled to sweeps/s at the
                  workload's N.  `literal_1thread` is the reference algorithm as written (member-list
                  recomputation, O(N^2 P) per sweep), timed at small N and EXTRAPOLATED.
   other_workloads  the other BASELINE configurations and the north-star shape in the same run
-                 (single GPU only): c2, c3, c4, ns (with its own cpu_baseline), four chains sharing
-                 one GPU, the PCIe-inclusive drop-in call, the rate from a random start.
+                 (single GPU only): c2, c3, c4, ns (each with its own cpu_baseline), four chains sharing
+                 one GPU, the PCIe-inclusive drop-in call at the north-star shape and at C5
+                 (ns_end_to_end, c5_end_to_end: host matrix in, S x N trace out, with the library's own
+                 phase clock), the rate from a random start.
+  multi_gpu      (N > 1) the launcher, the ranks the collective saw, the plane broadcast's milliseconds and
+                 every chain's own sweeps/s, so that a scaling record can be checked against its parts.
 """
 import argparse
 import json
@@ -174,6 +184,7 @@ def main():
         X = None
         if rank == 0:
             X, _ = synth.device_matrix(N, P, K_true, dseed, dev)
+        t_b0 = time.perf_counter()
         if x_layout == "bits":
             multi.broadcast_planes(ch, X, src=0)
             for c in chains[1:]:
@@ -184,6 +195,7 @@ def main():
             multi.broadcast_data(X, src=0)
             for c in chains:
                 c.set_data_device(X.data_ptr(), keepalive=X)
+        bcast_ms = 1e3 * (time.perf_counter() - t_b0)  # rank 0: pack + broadcast; others: receive
         for ci, c in enumerate(chains):
             rng = np.random.default_rng(multi.chain_seed(1000, rank * nchains + ci))
             if sampler == "collapsed":
@@ -219,6 +231,7 @@ def main():
         run(steps)
         for c in chains:
             c.sync()
+        t_own = time.perf_counter() - t0  # this rank's chains alone, before waiting for the others
         barrier()
         t1 = time.perf_counter()
         kern_ms, kern_n = ch.profile_read()
@@ -229,7 +242,9 @@ def main():
         kern_ms = multi.max_over_ranks(per_launch * lps * steps)  # resample-kernel ms over the timed sweeps
         return {"sampler": sampler, "K": K, "N": N, "P": P, "batch": ch.batch, "shape": ch.kernel_shape(),
                 "dt": multi.max_over_ranks(t1 - t0), "kern_ms": kern_ms, "kern_n": lps * steps, "lps": lps,
-                "X": X, "chains": chains, "layout": ch.x_layout(), "first": first, "nchains": nchains}
+                "X": X, "chains": chains, "layout": ch.x_layout(), "first": first, "nchains": nchains,
+                "bcast_ms": multi.max_over_ranks(bcast_ms),
+                "rank_sweeps_per_s": multi.gather_summaries([nchains * steps / t_own])[:, 0].tolist()}
 
     def close(m):
         for c in m["chains"][1:] + m["chains"][:1]:  # borrowers of the planes first
@@ -288,24 +303,28 @@ def main():
         cats = m["K"] + (1 if m["sampler"] == "dp" else 0)
         lds_tbps = (cats * G + own + cats) * 8 * N * steps / secs / 1e12
         lds_peak = 256 * 256 * 2.4e9 / 1e12
-        out.update({"bound": "valu_f64_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
-                    "hbm_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBS,
-                    "lds_TBps": lds_tbps, "lds_frac": lds_tbps / lds_peak, "group_width": gw,
+        # frac = SURVEY.md 8d's HBM fraction for the bytes this layout streams; the pipes that bind the kernel
+        # are reported beside it
+        out.update({"bound": "valu+lds (compute)", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBS,
+                    "lds_read_TBps": lds_tbps, "lds_read_frac_of_peak": lds_tbps / lds_peak, "group_width": gw,
                     "layout": "bit planes: %d bytes per observation and sweep" % (bps // N)})
         if vpw:
             ginst = vpw * (N / 64.0) * steps / secs / 1e9
-            out.update({"achieved": ginst, "frac": ginst / VALU_PEAK_GINST, "valu_inst_per_64_obs": vpw,
-                        "valu_source": info.get("source")})
-        else:
-            out.update({"achieved": None, "frac": None})
-        out["note"] = ("with X in bit planes the kernel streams 17x fewer bytes than the int32 layout and is bound by "
-                       "what it does per observation on the CU -- K*ceil(P/5) LDS table reads + fp64 adds, K "
-                       "exponentials -- not by HBM.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, "
-                       "profiles/) / launch time measured here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  lds_frac is "
-                       "the same for the LDS reads the scoring cannot avoid against 256 B/clk/CU (the PMC passes "
-                       "show the LDS pipe busy 65 % and the VALU 71 % of a launch: the two limits are co-binding).  "
-                       "hbm_frac is SURVEY.md 8d's figure for the bytes this layout streams; the HBM-bound kernel is "
-                       "other_workloads.c5_int32")
+            out.update({"valu_util": ginst / VALU_PEAK_GINST, "valu_G_wave_inst_per_s": ginst,
+                        "valu_peak_G_wave_inst_per_s": VALU_PEAK_GINST, "valu_inst_per_64_obs": vpw,
+                        "counters_source": info.get("source")})
+        for k in ("lds_busy", "lds_conflict_frac", "valu_busy"):
+            if info.get(k) is not None:
+                out[k] = info[k]
+        out["note"] = ("frac is SURVEY.md 8d's HBM fraction for the layout streamed: small by design -- with X in bit "
+                       "planes the kernel streams 17x fewer bytes than the int32 layout and is bound by what it does "
+                       "per observation on the CU (K*ceil(P/5) LDS table reads + fp64 adds, K exponentials).  "
+                       "valu_util = VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/) / launch time "
+                       "measured here / (1024 SIMDs x 2.4 GHz / 4 cycles): issue-slot utilisation of the instructions "
+                       "this kernel executes, not a fraction of algorithmic work.  lds_busy / lds_conflict_frac / "
+                       "valu_busy are the PMC passes' figures (profiles/): the two pipes are co-binding.  The "
+                       "HBM-bound kernel of the same workload is roofline_int32")
         return out
 
     def cpu_leg(sampler, Xdev, K, N, batch, label):
@@ -360,6 +379,29 @@ def main():
                         "N = 1000 and 2000 (%.3f s, %.3f s per sweep)" % (c, pts[0][1], pts[1][1])}
         return out
 
+    def end_to_end(Xh, K, nsamples, burnin, label):
+        """the drop-in call itself, host matrix in and S x N trace out, PCIe included (never `value`): twice --
+        the first call also pays for pinned staging and a stream that the library keeps for later calls -- with the
+        library's own phase clock of the second"""
+        import ctypes as C
+        from bmm_mcmc_amd import _capi
+        Nn = Xh.shape[0]
+        z0 = np.random.default_rng(0).integers(1, K + 1, Nn).astype(np.int32)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = bm.gibbs_collapsed(Xh, nsamples, K, burnin=burnin, seed=1, initial_K=z0)
+            times.append(time.perf_counter() - t0)
+        ms = (C.c_double * 6)()
+        _capi.lib().bmm_last_run_phases(ms)
+        names = ("pack_left_and_upload", "create_and_start_state", "enqueue", "device_wait", "trace_out", "release")
+        return {"workload": label, "sweeps_per_s": nsamples / times[1], "seconds": times[1], "first_call_seconds": times[0],
+                "kept_sweeps": int(out["z"].shape[0]), "host_threads": int(_capi.lib().bmm_host_threads()),
+                "phases_ms": {n: round(v, 3) for n, v in zip(names, ms)},
+                "note": "through the Python mirror of the R wrapper; X is validated and packed into bit planes by the "
+                        "host's cores while the chain is created, only the planes cross PCIe; the label trace leaves "
+                        "in blocks, one byte per label, widened on the host"}
+
     if args.shard:
         return bench_sharded(args, world, rank, local, dev, barrier)
     rs = 3 if (args.workload in ("c5", "ns", "c2") and args.chains_per_gpu == 1 and args.x_layout == "bits") else 0
@@ -394,6 +436,18 @@ def main():
                        "allocations_per_s": world * nch * args.steps * N / dt},
             "roofline": roofline_of(m, args.steps, key),
         }
+        if world > 1:
+            seen = int(multi.gather_summaries([1.0]).sum())
+            result["multi_gpu"] = {
+                "launcher": "torch.distributed.run: one process per GPU; the bit planes broadcast once from rank 0 "
+                            "(torch.distributed.broadcast, backend %s)" % ("gloo (REHEARSAL on one device, not a measurement)"
+                                                                          if rehearse else "nccl = RCCL"),
+                "ranks_seen_by_the_collective": seen, "world_size": world,
+                "plane_broadcast_ms": m["bcast_ms"],
+                "plane_bytes": 4 * ((P + 31) // 32) * N,
+                "per_rank_sweeps_per_s": m["rank_sweeps_per_s"],
+                "note": "value = all chains' sweeps / the slowest rank's time (barrier on both sides); per_rank_* is each "
+                        "rank's own clock around its own chains"}
         if m["first"]:
             result["from_random_start"] = {
                 "sweeps_per_s": m["first"],
@@ -405,6 +459,13 @@ def main():
         if not args.no_cpu and world == 1 and m["X"] is not None:
             result["cpu_baseline"] = cpu_leg(sampler, m["X"], K, N, batch, args.workload)
             result["config"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    c5_e2e = None
+    if (world == 1 and not args.no_extra and args.workload == "c5" and not (args.rows or args.k) and args.chains_per_gpu == 1
+            and m["X"] is not None and sampler == "collapsed"):
+        # C5 through the drop-in call: the same matrix, copied to the host (N x P column-major as R holds it)
+        Xh = m["X"].t().cpu().numpy()
+        c5_e2e = end_to_end(Xh, K, 30, 3, "gibbs_collapsed(host X 4 GB in, 30 sweeps, 27 kept: S x N trace 1.08 GB out) at C5, PCIe included")
+        del Xh
     close(m)
     del m
     # the other BASELINE points, measured in the same run (single GPU only).  Reported beside the
@@ -420,6 +481,12 @@ def main():
             extra["c5_int32"] = {"workload": "c5 with --x-layout int32 (X streamed as R hands it over)",
                                  "sweeps_per_s": args.steps / e["dt"], "ms_per_step": 1e3 * e["dt"] / args.steps,
                                  "batch": e["batch"], "roofline": r}
+            if r:
+                result["roofline_int32"] = dict(r, sweeps_per_s=args.steps / e["dt"],
+                                                note="the same workload on the kernel that streams the int32 matrix in place "
+                                                     "(bmm_chain_set_x_layout BMM_X_INT32): HBM-bound, carries the north star's "
+                                                     ">= 40 % of HBM roofline claim; the default bit-plane kernel is faster in "
+                                                     "sweeps/s and is what `value` reports")
             close(e)
             del e
         for w, steps in (("c2", 200), ("c3", 50), ("c4", 50), ("ns", 50)):
@@ -432,12 +499,15 @@ def main():
                         "allocations_per_s": steps * e["N"] / e["dt"],
                         "algorithmic_GBps": bps * steps / (e["kern_ms"] * 1e-3) / 1e9 if e["kern_ms"] else None,
                         "note": "working set %.0f MB: cache-resident, not an HBM measurement" % (bps / 1e6)}
-            if w == "ns":
-                if e["first"]:
-                    extra[w]["from_random_start_sweeps_per_s"] = e["first"]
-                if not args.no_cpu and e["X"] is not None:
-                    extra[w]["cpu_baseline"] = cpu_leg(e["sampler"], e["X"], e["K"], e["N"], e["batch"], "ns")
-                    extra[w]["gpu_over_cpu"] = extra[w]["sweeps_per_s"] / extra[w]["cpu_baseline"]["value"]
+            if w == "ns" and e["first"]:
+                extra[w]["from_random_start_sweeps_per_s"] = e["first"]
+            if not args.no_cpu and e["X"] is not None:
+                save = args.cpu_seconds
+                if w != "ns":
+                    args.cpu_seconds = min(save, 4.0)  # bounded: the default run must finish within minutes
+                extra[w]["cpu_baseline"] = cpu_leg(e["sampler"], e["X"], e["K"], e["N"], e["batch"], w)
+                args.cpu_seconds = save
+                extra[w]["gpu_over_cpu"] = extra[w]["sweeps_per_s"] / extra[w]["cpu_baseline"]["value"]
             close(e)
             del e
         # MCMC practice runs several chains: four resident chains on this GPU over one copy of the planes
@@ -450,16 +520,14 @@ def main():
         close(e)
         del e
         # the drop-in entry point end to end: host matrix in over PCIe, S x N trace out (never `value`)
-        Nn, Pn, Kn = 1_000_000, 50, 20
-        Xh, _, _, _ = synth.host_matrix(Nn, Pn, 20, 22)
-        z0 = np.random.default_rng(0).integers(1, Kn + 1, Nn).astype(np.int32)
-        t0 = time.perf_counter()
-        out = bm.gibbs_collapsed(Xh, 220, Kn, burnin=200, seed=1, initial_K=z0)
-        dt_api = time.perf_counter() - t0
-        extra["ns_end_to_end"] = {"workload": "gibbs_collapsed(host X 200 MB in, 220 sweeps, 20 kept: S x N trace "
-                                              "80 MB out) at the north-star shape, PCIe included",
-                                  "sweeps_per_s": 220 / dt_api, "seconds": dt_api, "kept_sweeps": int(out["z"].shape[0])}
-        del Xh, out
+        Xh, _, _, _ = synth.host_matrix(1_000_000, 50, 20, 22)
+        extra["ns_end_to_end"] = end_to_end(Xh, 20, 220, 200, "gibbs_collapsed(host X 200 MB in, 220 sweeps, 20 kept: S x N trace "
+                                                              "80 MB out) at the north-star shape, PCIe included")
+        extra["ns_end_to_end"]["vs_resident"] = extra["ns_end_to_end"]["sweeps_per_s"] / extra["ns"]["sweeps_per_s"]
+        del Xh
+        if c5_e2e:
+            c5_e2e["vs_resident"] = c5_e2e["sweeps_per_s"] / result["value"]
+            extra["c5_end_to_end"] = c5_e2e
         result["other_workloads"] = extra
     if rank == 0:
         print(json.dumps(result))

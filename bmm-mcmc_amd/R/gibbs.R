@@ -85,3 +85,11 @@ gibbs_stickbreaking <- function(data, nsamples, maxK, alpha=NULL, beta=0.5, gamm
           maxK, .bmm$conc(alpha), beta, gamma, a, b, s$burnin, relabel, s$burnrelabel, debug,
           seed, chains, devices)
 }
+
+# The reference prints "Sample j" at every sweep (src/collapsed_gibbs.cpp:85).  This build is silent unless
+# asked: bmm_progress(100) prints that line every 100 sweeps (with the current number of clusters for
+# gibbs_dp, src/collapsed_gibbs_dp.cpp:99), bmm_progress(0) turns it off again; debug = TRUE prints every sweep.
+# Returns the previous setting, invisibly.
+bmm_progress <- function(every = 0) {
+    invisible(.Call("_bmmmcmc_set_progress", PACKAGE = "bmmmcmc", as.integer(every)))
+}

@@ -142,7 +142,7 @@ def _multi(sampler, X, chains, devices, z0s, pi0s, th0s, nsamples, K, alpha, bet
     """bmm_multi_run: `chains` independent chains (seed + c) over one upload of the data."""
     N, P = X.shape
     S = nsamples - burnin
-    zs = [_np.zeros((S, N), dtype=_np.int32, order="F") for _ in range(chains)]
+    zs = [_np.empty((S, N), dtype=_np.int32, order="F") for _ in range(chains)]  # every cell is written by the library
     ths = [_np.zeros((K, P, S), order="F") for _ in range(chains)]
     als = [_np.zeros((S, 1), order="F") for _ in range(chains)]
     pis = [_np.zeros((S, K), order="F") for _ in range(chains)] if with_pi else None
@@ -195,7 +195,7 @@ def gibbs_collapsed(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1
         raise ValueError("initial_K must have one label per observation")
     S = nsamples - burnin
     rl = _Relabel(stephens, N, K, nsamples, burnin, _clamp_burnrelabel(burnrelabel, burnin)) if relabel else None
-    z = _np.zeros((S, N), dtype=_np.int32, order="F")
+    z = _np.empty((S, N), dtype=_np.int32, order="F")  # every cell is written by the library
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
     rc = _capi.lib().bmm_collapsed_run_probs(
@@ -228,7 +228,7 @@ def gibbs_dp(data, nsamples, alpha=None, a=1, b=1, beta=0.5, gamma=0.5, burnin=N
                       burnin, batch, seed, False)
     S = nsamples - burnin
     rl = _Relabel(stephens, N, maxK, nsamples, burnin, _clamp_burnrelabel(burnrelabel, burnin)) if relabel else None
-    z = _np.zeros((S, N), dtype=_np.int32, order="F")
+    z = _np.empty((S, N), dtype=_np.int32, order="F")  # every cell is written by the library
     theta = _np.zeros((maxK, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
     rc = _capi.lib().bmm_dp_run_probs(
@@ -277,7 +277,7 @@ def _explicit(sampler, fn, clamp, data, nsamples, K, alpha, beta, gamma, a, b, b
     S = nsamples - burnin
     W = _clamp_burnrelabel(burnrelabel, burnin) if clamp else int(burnrelabel)  # R/utils.R:97-101 has no clamp
     rl = _Relabel(stephens, N, K, nsamples, burnin, W) if relabel else None
-    z = _np.zeros((S, N), dtype=_np.int32, order="F")
+    z = _np.empty((S, N), dtype=_np.int32, order="F")  # every cell is written by the library
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
     pi = _np.zeros((S, K), order="F")

@@ -426,6 +426,7 @@ struct bmm_chain {
     int device = 0;
     hipStream_t stream = nullptr;
     bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
+    bool plain_stream = false;     // ... or is an ordinary non-blocking stream, which the pool takes back
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
@@ -574,6 +575,31 @@ int device_cus(int device) {
     return cus[device];
 }
 
+// Plain streams outlive their chain: creating and destroying one costs about 2 ms each on this runtime
+// (tools/hipcost_probe.hip), a fifth of what the rest of a 220-sweep drop-in call at the north-star shape
+// spends outside its sweeps.  A destroyed chain's (idle) plain stream goes back here, up to four per device;
+// streams with a hardware queue of their own (chains sharing a device) are created and destroyed as before.
+struct StreamPool {
+    std::mutex m;
+    std::vector<hipStream_t> idle[64];
+    hipStream_t get(int device) {
+        if (device < 0 || device >= 64) return nullptr;
+        std::lock_guard<std::mutex> g(m);
+        if (idle[device].empty()) return nullptr;
+        hipStream_t s = idle[device].back();
+        idle[device].pop_back();
+        return s;
+    }
+    bool put(int device, hipStream_t s) {
+        if (device < 0 || device >= 64) return false;
+        std::lock_guard<std::mutex> g(m);
+        if (idle[device].size() >= 4) return false;
+        idle[device].push_back(s);
+        return true;
+    }
+};
+StreamPool& stream_pool() { static StreamPool* const pool = new StreamPool(); return *pool; }  // never destroyed: no HIP call at exit
+
 int chain_stream_create(bmm_chain* c, bool dedicated) {
     int mode = dedicated ? BMM_STREAM_MODE : 0;
     if (const char* m = dbg_env("BMM_DEBUG_STREAM")) mode = atoi(m);
@@ -589,13 +615,23 @@ int chain_stream_create(bmm_chain* c, bool dedicated) {
         const int cus = device_cus(c->device);
         e = cus > 0 ? hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask) : hipErrorUnknown;
     }
-    if (e != hipSuccess) {
+    bool plain = false;
+    if (e != hipSuccess) {  // mode 0, or the special stream could not be had
         (void)hipGetLastError();
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        st = stream_pool().get(c->device);
+        if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        plain = true;
     }
     c->stream = st;
     c->dedicated_queue = dedicated;
+    c->plain_stream = plain;
     return BMM_OK;
+}
+// an idle plain stream goes back to the pool, anything else is destroyed
+void chain_stream_release(int device, hipStream_t st, bool plain) {
+    if (!st) return;
+    if (plain && stream_pool().put(device, st)) return;
+    (void)hipStreamDestroy(st);
 }
 
 // A chain that starts sharing its device with another one moves to a stream with a hardware queue of its
@@ -605,10 +641,11 @@ int chain_dedicated_queue(bmm_chain* c) {
     if (c->dedicated_queue || c->started) return BMM_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t old = c->stream;
+    const bool old_plain = c->plain_stream;
     if (old) HIP_TRY(hipStreamSynchronize(old));
     int rc = chain_stream_create(c, true);
-    if (rc) { c->stream = old; return rc; }
-    if (old) (void)hipStreamDestroy(old);
+    if (rc) { c->stream = old; c->plain_stream = old_plain; return rc; }
+    chain_stream_release(c->device, old, old_plain);
     return BMM_OK;
 }
 
@@ -1047,7 +1084,7 @@ void bmm_chain_destroy(bmm_chain* c) {
     void* bufs[] = {c->dX_owned, c->arena, c->run_arena, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    chain_stream_release(c->device, c->stream, c->plain_stream);  // synchronised above
     delete c;
 }
 
@@ -1918,6 +1955,25 @@ int bmm_full_run_probs(const int32_t* X, int64_t N, int P, const double* initial
 }
 
 // ---- several independent chains in one call (SURVEY.md section 8 rows b, e) ----------------
+// Where bmm_multi_run puts things, as pure bookkeeping (no device is touched; tests/test_capi_cpu.py): the
+// distinct devices in first-use order -- the RCCL broadcast list, root first -- and for every chain the chain
+// that holds its device's copy of the bit planes (the first chain on that device; a holder names itself).
+int bmm_multi_plan(int n_chains, const int* devices, int* n_devices_out, int* devices_out, int* holder_of_chain) {
+    if (n_chains < 1 || !n_devices_out || !devices_out || !holder_of_chain) return set_err(BMM_E_ARG, "bad argument");
+    int nd = 0;
+    for (int c = 0; c < n_chains; ++c) {
+        const int d = devices ? devices[c] : 0;
+        if (d < 0) return set_err(BMM_E_ARG, "devices[%d] = %d is not a device index", c, d);
+        int first = -1;
+        for (int e = 0; e < c && first < 0; ++e)
+            if ((devices ? devices[e] : 0) == d) first = e;
+        holder_of_chain[c] = first < 0 ? c : holder_of_chain[first];
+        if (first < 0) devices_out[nd++] = d;
+    }
+    *n_devices_out = nd;
+    return BMM_OK;
+}
+
 int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* X, int64_t N, int P,
                   const int32_t* const* initialK, const double* const* initialPi,
                   const double* const* initialTheta, int nsamples, int K, double alpha, double beta,
@@ -1940,13 +1996,13 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
             if (rc) return rc;
         }
         // chain c lives on devices[c] (device 0 when the table is null); distinct devices in first-use order
-        std::vector<int> dev_of((size_t)n_chains), devs;
-        for (int c = 0; c < n_chains; ++c) {
-            const int d = devices ? devices[c] : 0;
-            dev_of[(size_t)c] = d;
-            bool seen = false;
-            for (int e : devs) seen = seen || e == d;
-            if (!seen) devs.push_back(d);
+        std::vector<int> dev_of((size_t)n_chains), devs((size_t)n_chains), holder_idx((size_t)n_chains);
+        int ndev = 0;
+        {
+            int rcp = bmm_multi_plan(n_chains, devices, &ndev, devs.data(), holder_idx.data());
+            if (rcp) return rcp;
+            devs.resize((size_t)ndev);
+            for (int c = 0; c < n_chains; ++c) dev_of[(size_t)c] = devices ? devices[c] : 0;
         }
         std::vector<bmm_chain*> chains((size_t)n_chains, nullptr);
         struct Guard {
@@ -1965,7 +2021,7 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
         std::vector<bmm_chain*> holder(devs.size(), nullptr);  // first chain of each device: owns its planes
         for (size_t q = 0; q < devs.size(); ++q)
             for (int c = 0; c < n_chains && !holder[q]; ++c)
-                if (dev_of[(size_t)c] == devs[q]) holder[q] = chains[(size_t)c];
+                if (holder_idx[(size_t)c] == c && dev_of[(size_t)c] == devs[q]) holder[q] = chains[(size_t)c];
         rc = bmm_chain_set_data_host(holder[0], X);
         if (rc) return rc;
         if (devs.size() > 1) {
@@ -1977,11 +2033,9 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
             for (size_t q = 1; q < devs.size() && rc == BMM_OK; ++q) rc = bmm_chain_planes_filled(holder[q]);
             if (rc) return rc;
         }
-        for (int c = 0; c < n_chains; ++c) {
-            bmm_chain* ch = chains[(size_t)c];
-            if (ch->have_data) continue;
-            for (size_t q = 0; q < devs.size(); ++q)
-                if (devs[q] == dev_of[(size_t)c]) rc = bmm_chain_share_data(ch, holder[q]);
+        for (int c = 0; c < n_chains; ++c) {  // every other chain shares its device's copy
+            if (holder_idx[(size_t)c] == c) continue;
+            rc = bmm_chain_share_data(chains[(size_t)c], chains[(size_t)holder_idx[(size_t)c]]);
             if (rc) return rc;
         }
         // one host thread per chain; each enqueues on its own stream, so chains on one device overlap

@@ -110,17 +110,24 @@ def max_over_ranks(x):
     return float(t.item())
 
 
-def run_chains(sampler, X, K, nsweeps, base_seed=1000, batch=None, run_fn=None, **prior):
-    """Run one chain on this rank over the (already broadcast) data and gather the sorted
-    cluster proportions of every chain.  `run_fn(sampler, X, K, nsweeps, seed, batch, **prior)`
-    must return final 1-based labels; the default is the HIP chain on this rank's GPU."""
+def run_chains(sampler, X, K, nsweeps, base_seed=1000, batch=None, run_fn=None, chains_per_rank=1, **prior):
+    """Run `chains_per_rank` chains on this rank over the (already broadcast) data and gather the sorted cluster
+    proportions of every chain of the job.  Chain c of rank r is chain r * chains_per_rank + c of the job and
+    runs under key base_seed + that index (bmm_multi_run's numbering: seed + c).
+    `run_fn(sampler, X, K, nsweeps, seed, batch, **prior)` must return final 1-based labels; the default is
+    the HIP chain on this rank's GPU.  Returns (labels -- an array, or a list of arrays when chains_per_rank > 1 --
+    and the (world * chains_per_rank, K) summaries, rows in job order, identical on every rank)."""
     w, r, l = world()
-    seed = chain_seed(base_seed, r)
     if run_fn is None:
         run_fn = _hip_chain
-    z = np.asarray(run_fn(sampler, X, K, nsweeps, seed, batch, **prior))
-    props = np.sort(np.bincount(z[z > 0] - 1, minlength=K)[:K] / max(1, (z > 0).sum()))[::-1]
-    return z, gather_summaries(props)
+    zs, props = [], []
+    for c in range(int(chains_per_rank)):
+        seed = chain_seed(base_seed, r * int(chains_per_rank) + c)
+        z = np.asarray(run_fn(sampler, X, K, nsweeps, seed, batch, **prior))
+        zs.append(z)
+        props.append(np.sort(np.bincount(z[z > 0] - 1, minlength=K)[:K] / max(1, (z > 0).sum()))[::-1])
+    summ = gather_summaries(np.concatenate(props)).reshape(-1, K)  # rank-major, then chain: job order
+    return (zs[0] if chains_per_rank == 1 else zs), summ
 
 
 def _hip_chain(sampler, X, K, nsweeps, seed, batch, **prior):

@@ -16,7 +16,19 @@
  *   _bmmmcmc_my_stephens_batch 2; RcppExports.cpp:140,142,143): stand-alone they raise a clear R
  *   error; with -DBMM_SHIM_FORWARD they are the package's own functions, linked in beside the shim
  *   (INTEGRATION.md section 1 shows the two Makevars lines that rename the generated file's
- *   R_init_bmmmcmc and its four sampler wrappers out of the way -- no source of the package is edited).
+ *   R_init_bmmmcmc and its four sampler wrappers out of the way -- no source of the package is edited);
+ *
+ *   relabel = TRUE: with -DBMM_SHIM_FORWARD every sampler entry point hands such a call to relabel_glue.cpp
+ *   (bmm_glue_*_relabel, C++ on Rcpp/RcppArmadillo beside the package's own stephens.cpp), which runs
+ *   bmm_*_run_probs and feeds the package's unchanged Stephens code; stand-alone (no package objects to
+ *   call) it is an R error that says so;
+ *
+ *   _bmmmcmc_set_progress(every): the reference prints "Sample j" at every sweep (collapsed_gibbs.cpp:85);
+ *   here a run is silent unless this was called with every > 0 (or debug = TRUE: every sweep).
+ *
+ * `df` may be any numeric matrix: Rcpp's IntegerMatrix parameter coerces a REALSXP (what matrix(c(0, 1, ...))
+ * is in R) or logical matrix (RcppExports.cpp:15,38,70,118), and so does this shim (coerceVector under
+ * PROTECT; an INTSXP is used in place, no copy).
  *
  * R is not installed in the build image: tests/test_r_shim.py syntax-checks this file against a
  * test-only declaration header of the R API symbols it uses and compares the registration table
@@ -41,8 +53,20 @@
 #define MAX_CHAINS 64
 
 /* ---------------------------------------------------------------- small helpers */
-static void need_int_matrix(SEXP df) {
-    if (TYPEOF(df) != INTSXP || !isMatrix(df)) error("data must be an integer matrix");
+/* df as an INTSXP matrix: itself, or a coerced copy the caller keeps PROTECTed (*nprot is bumped).  What
+ * Rcpp::traits::input_parameter<IntegerMatrix> does for the reference (src/RcppExports.cpp:15). */
+static SEXP as_int_matrix(SEXP df, int* nprot) {
+    if (!isMatrix(df)) error("data must be a matrix with one observation per row");
+    switch (TYPEOF(df)) {
+        case INTSXP: return df;
+        case REALSXP: case LGLSXP: case RAWSXP: {
+            SEXP x = PROTECT(coerceVector(df, INTSXP));
+            ++*nprot;
+            return x;
+        }
+        default: error("data must be a numeric (0/1) matrix");
+    }
+    return R_NilValue; /* not reached */
 }
 
 static SEXP na_perm(int S, int K) { /* the reference returns uninitialised memory here */
@@ -71,10 +95,51 @@ static SEXP cube(int a, int b, int c) {
     return x;
 }
 
-static void no_relabel(SEXP relabel) {
-    if (asLogical(relabel) == TRUE)
-        error("relabel=TRUE feeds the package's own Stephens code (src/stephens.cpp) from "
-              "bmm_*_run_probs: build r-shim/relabel_glue.cpp into the package (INTEGRATION.md section 2)");
+/* relabel = TRUE runs the package's own Stephens code (src/stephens.cpp) on the probability matrices
+ * bmm_*_run_probs produce: that needs the package's objects and relabel_glue.cpp beside this shim
+ * (-DBMM_SHIM_FORWARD).  One chain per call. */
+static int wants_relabel(SEXP relabel, int chains) {
+    if (asLogical(relabel) != TRUE) return 0;
+#ifndef BMM_SHIM_FORWARD
+    error("relabel=TRUE feeds the package's own Stephens code (src/stephens.cpp) from bmm_*_run_probs: build "
+          "this shim with -DBMM_SHIM_FORWARD and r-shim/relabel_glue.cpp into the package (INTEGRATION.md section 2)");
+#endif
+    if (chains != 1) error("relabel=TRUE is offered for one chain per call");
+    return 1;
+}
+#ifdef BMM_SHIM_FORWARD
+/* relabel_glue.cpp: the reference's argument lists (relabel and debug dropped) + seed, batch, device */
+extern SEXP bmm_glue_collapsed_relabel(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta, SEXP gamma,
+                                       SEXP a, SEXP b, SEXP burnin, SEXP burnrelabel, SEXP seed, SEXP batch, SEXP device);
+extern SEXP bmm_glue_dp_relabel(SEXP df, SEXP nsamples, SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
+                                SEXP burnrelabel, SEXP maxK, SEXP seed, SEXP batch, SEXP device);
+extern SEXP bmm_glue_sb_relabel(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK, SEXP alpha, SEXP beta,
+                                SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP burnrelabel, SEXP seed, SEXP device);
+extern SEXP bmm_glue_full_relabel(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta,
+                                  SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP burnrelabel, SEXP seed, SEXP device);
+static SEXP real_scalar(double v) { return ScalarReal(v); }
+#endif
+
+/* ---------------------------------------------------------------- progress */
+static int g_progress_every = 0;
+static int shim_progress(void* user, int sample, int nsamples, int k_used) {
+    if (k_used >= 0) Rprintf("Sample %d\tK: %d\n", sample, k_used); /* collapsed_gibbs_dp.cpp:99 */
+    else Rprintf("Sample %d\n", sample);                             /* collapsed_gibbs.cpp:85 */
+    return 0;
+}
+/* the hook is on for the duration of one run: every `every` sweeps when _bmmmcmc_set_progress asked for it,
+ * every sweep when debug = TRUE (the reference prints every sweep and, with debug, much more) */
+static void progress_on(SEXP debug) {
+    const int every = asLogical(debug) == TRUE ? 1 : g_progress_every;
+    bmm_set_progress(every > 0 ? shim_progress : NULL, NULL, every);
+}
+static void progress_off(void) { bmm_set_progress(NULL, NULL, 0); }
+SEXP _bmmmcmc_set_progress(SEXP every) {
+    const int e = asInteger(every);
+    if (e == NA_INTEGER || e < 0) error("every must be a non-negative whole number (0 = silent)");
+    const int old = g_progress_every;
+    g_progress_every = e;
+    return ScalarInteger(old);
 }
 
 /* one 53-bit integer from R's stream: set.seed() determines the chain */
@@ -122,7 +187,7 @@ typedef struct {
 } dims_t;
 
 static dims_t dims_of(SEXP df, SEXP nsamples, SEXP K, SEXP burnin) {
-    need_int_matrix(df);
+    if (!isMatrix(df)) error("data must be a matrix with one observation per row");
     dims_t d;
     d.N = nrows(df); d.P = ncols(df); d.ns = asInteger(nsamples); d.K = asInteger(K); d.bi = asInteger(burnin);
     d.S = d.ns - d.bi;
@@ -134,11 +199,12 @@ static dims_t dims_of(SEXP df, SEXP nsamples, SEXP K, SEXP burnin) {
 /* ---------------------------------------------------------------- the counting samplers */
 /* sampler: BMM_SAMPLER_COLLAPSED (initialK: N x chains integer) or BMM_SAMPLER_DP (initialK unused) */
 static SEXP counting_run(int sampler, SEXP df, SEXP initialK, dims_t d, SEXP alpha, SEXP beta, SEXP gamma,
-                         SEXP a, SEXP b, uint64_t seed, int64_t batch, int chains, const int* dev) {
+                         SEXP a, SEXP b, uint64_t seed, int64_t batch, int chains, const int* dev, SEXP debug) {
     const int32_t* z0[MAX_CHAINS];
     int32_t* zs[MAX_CHAINS];
     double *ths[MAX_CHAINS], *als[MAX_CHAINS];
     int nprot = 0;
+    SEXP x = as_int_matrix(df, &nprot);
     SEXP z0s = R_NilValue;
     if (sampler == BMM_SAMPLER_COLLAPSED) {
         z0s = PROTECT(coerceVector(initialK, INTSXP)); ++nprot;
@@ -156,39 +222,70 @@ static SEXP counting_run(int sampler, SEXP df, SEXP initialK, dims_t d, SEXP alp
         zs[c] = INTEGER(z); ths[c] = REAL(th); als[c] = REAL(al);
     }
     int rc;
+    progress_on(debug);
     if (chains == 1 && sampler == BMM_SAMPLER_COLLAPSED)
-        rc = bmm_collapsed_run(INTEGER(df), d.N, d.P, z0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma),
+        rc = bmm_collapsed_run(INTEGER(x), d.N, d.P, z0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma),
                                asReal(a), asReal(b), d.bi, batch, seed, dev ? dev[0] : 0, zs[0], ths[0], als[0]);
     else if (chains == 1)
-        rc = bmm_dp_run(INTEGER(df), d.N, d.P, d.ns, asReal(alpha), asReal(beta), asReal(gamma), asReal(a), asReal(b),
+        rc = bmm_dp_run(INTEGER(x), d.N, d.P, d.ns, asReal(alpha), asReal(beta), asReal(gamma), asReal(a), asReal(b),
                         d.bi, d.K, batch, seed, dev ? dev[0] : 0, zs[0], ths[0], als[0]);
     else
-        rc = bmm_multi_run(sampler, chains, dev, INTEGER(df), d.N, d.P, sampler == BMM_SAMPLER_COLLAPSED ? z0 : NULL,
+        rc = bmm_multi_run(sampler, chains, dev, INTEGER(x), d.N, d.P, sampler == BMM_SAMPLER_COLLAPSED ? z0 : NULL,
                            NULL, NULL, d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma), asReal(a), asReal(b),
                            d.bi, batch, seed, NULL, zs, ths, als);
+    progress_off();
     if (rc) { UNPROTECT(nprot); error("%s", bmm_last_error()); }
     SEXP ret = chains == 1 ? VECTOR_ELT(out, 0) : out; /* one chain: the reference's list itself */
     UNPROTECT(nprot);
     return ret;
 }
 
+/* relabel = TRUE: the call goes to relabel_glue.cpp with the seed, batch and device this shim resolved */
+#ifdef BMM_SHIM_FORWARD
+static SEXP relabel_counting(int sampler, SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta, SEXP gamma,
+                             SEXP a, SEXP b, SEXP burnin, SEXP burnrelabel, uint64_t seed, int64_t batch, int device) {
+    SEXP s = PROTECT(real_scalar((double)seed)), bt = PROTECT(real_scalar((double)batch)), dv = PROTECT(ScalarInteger(device));
+    SEXP r = sampler == BMM_SAMPLER_COLLAPSED
+                 ? bmm_glue_collapsed_relabel(df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin, burnrelabel, s, bt, dv)
+                 : bmm_glue_dp_relabel(df, nsamples, alpha, beta, gamma, a, b, burnin, burnrelabel, K, s, bt, dv);
+    UNPROTECT(3);
+    return r;
+}
+static SEXP relabel_explicit(int sampler, SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha,
+                             SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP burnrelabel, uint64_t seed, int device) {
+    SEXP s = PROTECT(real_scalar((double)seed)), dv = PROTECT(ScalarInteger(device));
+    SEXP r = (sampler == BMM_SAMPLER_FULL ? bmm_glue_full_relabel : bmm_glue_sb_relabel)(
+        df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin, burnrelabel, s, dv);
+    UNPROTECT(2);
+    return r;
+}
+#else
+#define relabel_counting(...) R_NilValue /* wants_relabel() has raised the error */
+#define relabel_explicit(...) R_NilValue
+#endif
+
 /* collapsed_gibbs_cpp(df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, debug)
  * -- src/RcppExports.cpp:10, 13 arguments */
 SEXP _bmmmcmc_collapsed_gibbs_cpp(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta,
                                   SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
                                   SEXP debug) {
-    no_relabel(relabel);
+    if (wants_relabel(relabel, 1))
+        return relabel_counting(BMM_SAMPLER_COLLAPSED, df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin,
+                                burnrelabel, seed_from_r(), 0, 0);
     return counting_run(BMM_SAMPLER_COLLAPSED, df, initialK, dims_of(df, nsamples, K, burnin), alpha, beta, gamma, a, b,
-                        seed_from_r(), 0, 1, NULL);
+                        seed_from_r(), 0, 1, NULL, debug);
 }
 SEXP _bmmmcmc_collapsed_gibbs_ex(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta, SEXP gamma,
                                  SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP debug,
                                  SEXP seed, SEXP batch, SEXP chains, SEXP devices) {
-    no_relabel(relabel);
     int dev[MAX_CHAINS];
     const int n = chains_arg(chains);
+    const int* dv = devices_arg(devices, n, dev);
+    if (wants_relabel(relabel, n))
+        return relabel_counting(BMM_SAMPLER_COLLAPSED, df, initialK, nsamples, K, alpha, beta, gamma, a, b, burnin,
+                                burnrelabel, seed_arg(seed), batch_arg(batch), dv ? dv[0] : 0);
     return counting_run(BMM_SAMPLER_COLLAPSED, df, initialK, dims_of(df, nsamples, K, burnin), alpha, beta, gamma, a, b,
-                        seed_arg(seed), batch_arg(batch), n, devices_arg(devices, n, dev));
+                        seed_arg(seed), batch_arg(batch), n, dv, debug);
 }
 
 /* collapsed_gibbs_dp_cpp(df, nsamples, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, maxK, debug)
@@ -196,28 +293,34 @@ SEXP _bmmmcmc_collapsed_gibbs_ex(SEXP df, SEXP initialK, SEXP nsamples, SEXP K, 
 SEXP _bmmmcmc_collapsed_gibbs_dp_cpp(SEXP df, SEXP nsamples, SEXP alpha, SEXP beta, SEXP gamma, SEXP a,
                                      SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP maxK,
                                      SEXP debug) {
-    no_relabel(relabel);
+    if (wants_relabel(relabel, 1))
+        return relabel_counting(BMM_SAMPLER_DP, df, R_NilValue, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
+                                burnrelabel, seed_from_r(), 0, 0);
     return counting_run(BMM_SAMPLER_DP, df, R_NilValue, dims_of(df, nsamples, maxK, burnin), alpha, beta, gamma, a, b,
-                        seed_from_r(), 0, 1, NULL);
+                        seed_from_r(), 0, 1, NULL, debug);
 }
 SEXP _bmmmcmc_collapsed_gibbs_dp_ex(SEXP df, SEXP nsamples, SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b,
                                     SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP maxK, SEXP debug,
                                     SEXP seed, SEXP batch, SEXP chains, SEXP devices) {
-    no_relabel(relabel);
     int dev[MAX_CHAINS];
     const int n = chains_arg(chains);
+    const int* dv = devices_arg(devices, n, dev);
+    if (wants_relabel(relabel, n))
+        return relabel_counting(BMM_SAMPLER_DP, df, R_NilValue, nsamples, maxK, alpha, beta, gamma, a, b, burnin,
+                                burnrelabel, seed_arg(seed), batch_arg(batch), dv ? dv[0] : 0);
     return counting_run(BMM_SAMPLER_DP, df, R_NilValue, dims_of(df, nsamples, maxK, burnin), alpha, beta, gamma, a, b,
-                        seed_arg(seed), batch_arg(batch), n, devices_arg(devices, n, dev));
+                        seed_arg(seed), batch_arg(batch), n, dv, debug);
 }
 
 /* ---------------------------------------------------------------- the explicit-parameter samplers */
 /* initialPi: K x chains, initialTheta: (K*P) x chains (each column a K x P matrix, column-major) */
 static SEXP explicit_run(int sampler, SEXP df, SEXP initialPi, SEXP initialTheta, dims_t d, SEXP alpha, SEXP beta,
-                         SEXP gamma, SEXP a, SEXP b, uint64_t seed, int chains, const int* dev) {
+                         SEXP gamma, SEXP a, SEXP b, uint64_t seed, int chains, const int* dev, SEXP debug) {
     const double *pi0[MAX_CHAINS], *th0[MAX_CHAINS];
     int32_t* zs[MAX_CHAINS];
     double *ths[MAX_CHAINS], *als[MAX_CHAINS], *pis[MAX_CHAINS];
     int nprot = 0;
+    SEXP x = as_int_matrix(df, &nprot);
     SEXP p0 = PROTECT(coerceVector(initialPi, REALSXP)), t0 = PROTECT(coerceVector(initialTheta, REALSXP));
     nprot += 2;
     const R_xlen_t kp = (R_xlen_t)d.K * d.P;
@@ -238,13 +341,15 @@ static SEXP explicit_run(int sampler, SEXP df, SEXP initialPi, SEXP initialTheta
         zs[c] = INTEGER(z); ths[c] = REAL(th); als[c] = REAL(al); pis[c] = REAL(pi);
     }
     int rc;
+    progress_on(debug);
     if (chains == 1)
         rc = (sampler == BMM_SAMPLER_FULL ? bmm_full_run : bmm_sb_run)(
-            INTEGER(df), d.N, d.P, pi0[0], th0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma), asReal(a),
+            INTEGER(x), d.N, d.P, pi0[0], th0[0], d.ns, d.K, asReal(alpha), asReal(beta), asReal(gamma), asReal(a),
             asReal(b), d.bi, seed, dev ? dev[0] : 0, pis[0], zs[0], ths[0], als[0]);
     else
-        rc = bmm_multi_run(sampler, chains, dev, INTEGER(df), d.N, d.P, NULL, pi0, th0, d.ns, d.K, asReal(alpha),
+        rc = bmm_multi_run(sampler, chains, dev, INTEGER(x), d.N, d.P, NULL, pi0, th0, d.ns, d.K, asReal(alpha),
                            asReal(beta), asReal(gamma), asReal(a), asReal(b), d.bi, 0, seed, pis, zs, ths, als);
+    progress_off();
     if (rc) { UNPROTECT(nprot); error("%s", bmm_last_error()); }
     SEXP ret = chains == 1 ? VECTOR_ELT(out, 0) : out;
     UNPROTECT(nprot);
@@ -256,18 +361,23 @@ static SEXP explicit_run(int sampler, SEXP df, SEXP initialPi, SEXP initialTheta
 SEXP _bmmmcmc_gibbs_stickbreaking_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
                                       SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin,
                                       SEXP relabel, SEXP burnrelabel, SEXP debug) {
-    no_relabel(relabel);
+    if (wants_relabel(relabel, 1))
+        return relabel_explicit(BMM_SAMPLER_SB, df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b,
+                                burnin, burnrelabel, seed_from_r(), 0);
     return explicit_run(BMM_SAMPLER_SB, df, initialPi, initialTheta, dims_of(df, nsamples, maxK, burnin), alpha, beta,
-                        gamma, a, b, seed_from_r(), 1, NULL);
+                        gamma, a, b, seed_from_r(), 1, NULL, debug);
 }
 SEXP _bmmmcmc_gibbs_stickbreaking_ex(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP maxK,
                                      SEXP alpha, SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel,
                                      SEXP burnrelabel, SEXP debug, SEXP seed, SEXP chains, SEXP devices) {
-    no_relabel(relabel);
     int dev[MAX_CHAINS];
     const int n = chains_arg(chains);
+    const int* dv = devices_arg(devices, n, dev);
+    if (wants_relabel(relabel, n))
+        return relabel_explicit(BMM_SAMPLER_SB, df, initialPi, initialTheta, nsamples, maxK, alpha, beta, gamma, a, b,
+                                burnin, burnrelabel, seed_arg(seed), dv ? dv[0] : 0);
     return explicit_run(BMM_SAMPLER_SB, df, initialPi, initialTheta, dims_of(df, nsamples, maxK, burnin), alpha, beta,
-                        gamma, a, b, seed_arg(seed), n, devices_arg(devices, n, dev));
+                        gamma, a, b, seed_arg(seed), n, dv, debug);
 }
 
 /* gibbs_cpp(df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel,
@@ -275,18 +385,23 @@ SEXP _bmmmcmc_gibbs_stickbreaking_ex(SEXP df, SEXP initialPi, SEXP initialTheta,
 SEXP _bmmmcmc_gibbs_cpp(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha,
                         SEXP beta, SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel,
                         SEXP debug) {
-    no_relabel(relabel);
+    if (wants_relabel(relabel, 1))
+        return relabel_explicit(BMM_SAMPLER_FULL, df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b,
+                                burnin, burnrelabel, seed_from_r(), 0);
     return explicit_run(BMM_SAMPLER_FULL, df, initialPi, initialTheta, dims_of(df, nsamples, K, burnin), alpha, beta,
-                        gamma, a, b, seed_from_r(), 1, NULL);
+                        gamma, a, b, seed_from_r(), 1, NULL, debug);
 }
 SEXP _bmmmcmc_gibbs_ex(SEXP df, SEXP initialPi, SEXP initialTheta, SEXP nsamples, SEXP K, SEXP alpha, SEXP beta,
                        SEXP gamma, SEXP a, SEXP b, SEXP burnin, SEXP relabel, SEXP burnrelabel, SEXP debug,
                        SEXP seed, SEXP chains, SEXP devices) {
-    no_relabel(relabel);
     int dev[MAX_CHAINS];
     const int n = chains_arg(chains);
+    const int* dv = devices_arg(devices, n, dev);
+    if (wants_relabel(relabel, n))
+        return relabel_explicit(BMM_SAMPLER_FULL, df, initialPi, initialTheta, nsamples, K, alpha, beta, gamma, a, b,
+                                burnin, burnrelabel, seed_arg(seed), dv ? dv[0] : 0);
     return explicit_run(BMM_SAMPLER_FULL, df, initialPi, initialTheta, dims_of(df, nsamples, K, burnin), alpha, beta,
-                        gamma, a, b, seed_arg(seed), n, devices_arg(devices, n, dev));
+                        gamma, a, b, seed_arg(seed), n, dv, debug);
 }
 
 /* ---------------------------------------------------------------- the entry points this build does not touch */
@@ -320,6 +435,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_bmmmcmc_collapsed_gibbs_dp_ex", (DL_FUNC)&_bmmmcmc_collapsed_gibbs_dp_ex, 16},
     {"_bmmmcmc_gibbs_ex", (DL_FUNC)&_bmmmcmc_gibbs_ex, 17},
     {"_bmmmcmc_gibbs_stickbreaking_ex", (DL_FUNC)&_bmmmcmc_gibbs_stickbreaking_ex, 17},
+    {"_bmmmcmc_set_progress", (DL_FUNC)&_bmmmcmc_set_progress, 1},
     {NULL, NULL, 0}};
 
 void R_init_bmmmcmc(DllInfo* dll) {

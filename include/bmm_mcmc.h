@@ -193,6 +193,12 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
                   double beta, double gamma, double a, double b, int burnin, int64_t batch, uint64_t seed,
                   double* const* pi_out, int32_t* const* z_out, double* const* theta_out,
                   double* const* alpha_out);
+/* Where bmm_multi_run puts things for a device table (NULL: every chain on device 0), as pure bookkeeping --
+ * no device is touched: devices_out[0 .. *n_devices_out) = the distinct devices in first-use order (the
+ * broadcast list of the one ncclBroadcast, root first: devices_out[0] packs the data), holder_of_chain[c] =
+ * the chain that holds the copy of the bit planes chain c reads (the first chain on c's device; a holder
+ * names itself, every other chain shares with bmm_chain_share_data).  Both outputs have room for n_chains. */
+int bmm_multi_plan(int n_chains, const int* devices, int* n_devices_out, int* devices_out, int* holder_of_chain);
 /* The broadcast of bmm_multi_run on a test pattern of `words` 32-bit words over the listed distinct
  * devices, compared afterwards on every one of them.  With one device the collective still runs
  * (library opened, communicator of one rank, ncclBroadcast): what a one-GPU box can check. */

@@ -8,9 +8,11 @@
 typedef struct SEXPREC* SEXP;
 typedef ptrdiff_t R_xlen_t;
 typedef enum { FALSE = 0, TRUE } Rboolean;
+#define LGLSXP 10
 #define INTSXP 13
 #define REALSXP 14
 #define STRSXP 16
+#define RAWSXP 24
 #define VECSXP 19
 extern SEXP R_NilValue, R_NamesSymbol;
 extern int R_NaInt;
@@ -25,6 +27,8 @@ double Rf_asReal(SEXP);
 SEXP Rf_allocVector(unsigned int, R_xlen_t), Rf_allocMatrix(unsigned int, int, int), Rf_allocArray(unsigned int, SEXP);
 SEXP Rf_coerceVector(SEXP, unsigned int), Rf_mkChar(const char*), Rf_setAttrib(SEXP, SEXP, SEXP);
 SEXP Rf_protect(SEXP);
+SEXP Rf_ScalarReal(double), Rf_ScalarInteger(int);
+void Rprintf(const char*, ...) __attribute__((format(printf, 1, 2)));
 void Rf_unprotect(int);
 void Rf_error(const char*, ...) __attribute__((noreturn, format(printf, 1, 2)));
 int* INTEGER(SEXP);
@@ -47,4 +51,6 @@ void SET_STRING_ELT(SEXP, R_xlen_t, SEXP);
 #define coerceVector Rf_coerceVector
 #define mkChar Rf_mkChar
 #define setAttrib Rf_setAttrib
+#define ScalarReal Rf_ScalarReal
+#define ScalarInteger Rf_ScalarInteger
 #endif

@@ -117,3 +117,27 @@ def test_group_width_rule_is_the_oracles(oracle):
     assert L.bmm_spec_group_width_for(2, 50, 50) == 5 and L.bmm_spec_group_width_for(0, 3, 20) == 5    # C4, C2
     assert L.bmm_spec_group_width_for(0, 20, 128) == 4 and L.bmm_spec_group_width_for(2, 64, 64) == 4
     assert L.bmm_spec_group_width_for(7, 3, 3) == -1
+
+
+def test_multi_run_placement_is_pure_bookkeeping():
+    """bmm_multi_plan: what bmm_multi_run does with a device table, without touching a device -- the distinct
+    devices in first-use order (the RCCL broadcast list, root first) and, per chain, the chain holding its
+    device's copy of the bit planes.  No multi-GPU box has run this path yet; its bookkeeping is held here."""
+    import ctypes as C
+    L = _capi.lib()
+
+    def plan(devs):
+        n = len(devs) if devs is not None else 5
+        tab = (C.c_int * n)(*devs) if devs is not None else None
+        nd, out, hold = C.c_int(0), (C.c_int * n)(), (C.c_int * n)()
+        rc = L.bmm_multi_plan(C.c_int(n), tab, C.byref(nd), out, hold)
+        return rc, list(out)[:nd.value], list(hold)
+
+    assert plan([0, 1, 0, 1]) == (0, [0, 1], [0, 1, 0, 1])
+    assert plan([3, 3, 3]) == (0, [3], [0, 0, 0])
+    assert plan([2, 0, 1, 0, 2, 7]) == (0, [2, 0, 1, 7], [0, 1, 2, 1, 0, 5])
+    assert plan(list(range(8))) == (0, list(range(8)), list(range(8)))           # the 8-GPU node: one chain per GPU
+    assert plan(None) == (0, [0], [0, 0, 0, 0, 0])                               # devices = NULL: all on device 0
+    rc, _, _ = plan([0, -1])
+    assert rc == 1 and b"devices[1]" in L.bmm_last_error()
+    assert L.bmm_multi_plan(C.c_int(0), None, None, None, None) == 1

@@ -110,6 +110,76 @@ def test_two_ranks_broadcast_seed_and_gather(oracle):
     assert mx0 == mx1 == 2.0
 
 
+def _worker4(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from bmm_mcmc_amd import multi
+    from util import synth
+    multi.init(backend="gloo")
+    P, N, K = 6, 300, 3
+    Xh, _, _, _ = synth(N, P, K, 21)
+    X = torch.from_numpy(np.ascontiguousarray(Xh.T)) if rank == 0 else torch.zeros((P, N), dtype=torch.int32)
+    stub = _PlanesStub(P, N)
+    multi.broadcast_planes(stub, X if rank == 0 else None, src=0)        # planes from rank 0 to three receivers
+    multi.broadcast_data(X, src=0)
+    zs, summ = multi.run_chains("collapsed", X, K, 12, base_seed=500, batch=32, run_fn=_oracle_chain, chains_per_rank=2)
+    q.put((rank, [z.tolist() for z in zs], summ.tolist(), int(stub.t.to(torch.int64).sum()), stub.filled,
+           multi.max_over_ranks(10.0 - rank)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_four_ranks_two_chains_each(oracle):
+    """world size 4, two chains per rank: chain r * 2 + c of the job runs under key base + r * 2 + c (the
+    numbering of bmm_multi_run), every rank receives the planes and sees all eight summaries in job order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from util import synth
+    Xh, _, _, _ = synth(300, 6, 3, 21)
+    Xt = torch.from_numpy(np.ascontiguousarray(Xh.T))
+    summaries = [g[2] for g in got]
+    assert all(s == summaries[0] for s in summaries) and len(summaries[0]) == 8
+    planes = {g[3] for g in got}
+    assert len(planes) == 1 and 0 not in planes                     # the same planes on all four ranks
+    assert [g[4] for g in got] == [False, True, True, True]         # receivers declared theirs filled
+    assert all(g[5] == 10.0 for g in got)
+    seen = []
+    for rank, zs, _, _, _, _ in got:
+        assert len(zs) == 2
+        for c, z in enumerate(zs):
+            want = _oracle_chain("collapsed", Xt, 3, 12, 500 + rank * 2 + c, 32)     # key = base + job index
+            assert z == want.tolist()
+            props = np.sort(np.bincount(np.array(z) - 1, minlength=3) / 300)[::-1]
+            np.testing.assert_allclose(summaries[0][rank * 2 + c], props)            # row = job index
+            seen.append(tuple(z))
+    assert len(set(seen)) == 8                                       # eight different chains
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """`python bench.py --gpus N` started without torch.distributed.run drives N devices from one process; with
+    fewer devices visible it must exit non-zero and say why (a SCALE run on a short node must not report numbers)"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--no-cpu", "--no-extra"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "64 GPUs asked for" in r.stderr and "visible" in r.stderr
+    assert r.stdout.strip() == ""                                    # no JSON line
+
+
 def test_single_process_helpers_need_no_group():
     from bmm_mcmc_amd import multi
     assert multi.world() == (1, 0, 0) or multi.world()[0] >= 1
