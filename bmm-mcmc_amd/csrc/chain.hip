@@ -270,6 +270,9 @@ constexpr int kThreadsLarge = 512;   // 256 VGPRs
 #ifndef BMM_STAGE_WIDE
 #define BMM_STAGE_WIDE 32
 #endif
+#ifndef BMM_SMALL_SPLIT
+#define BMM_SMALL_SPLIT 1  // short launches of 16-32 accumulators run two lanes per observation (pick_kernel)
+#endif
 constexpr int kStageWide = BMM_STAGE_WIDE;  // features in flight per wave where registers allow
 
 int pick_kt(int cats) {
@@ -362,6 +365,12 @@ constexpr int kThreadsSplit = 1024;
 template <int MINUS, int GW>
 resample_fn resample_kernel_split_w(int kt) {
     switch (kt) {
+        // 16 to 32 accumulators: for launches too short to give a wave more than a chunk or two (pick_kernel)
+        case 16: return GW == kGroupW ? k_resample<16, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
+        case 20: return GW == kGroupW ? k_resample<20, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
+        case 24: return GW == kGroupW ? k_resample<24, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
+        case 28: return GW == kGroupW ? k_resample<28, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
+        case 32: return GW == kGroupW ? k_resample<32, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
         case 40: return k_resample<40, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
         case 48: return k_resample<48, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
         case 56: return k_resample<56, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
@@ -869,10 +878,19 @@ int pick_kernel(bmm_chain* c) {
     const bool alt = p.W != kGroupW;  // the narrower groups: default-sized kernels only
     c->fn = resample_kernel(p.KT, minus, c->bits, p.W);
     int split = 1;
-    if (c->bits && p.KT > 32 && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
-        c->fn = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W);
-        c->NT = kThreadsSplit;
-        split = 2;
+    // Two lanes per observation: always above 32 accumulators (registers), and from 16 up when a launch is so
+    // short that the default form would give a wave at most a chunk or two -- then a launch is all latency
+    // (the north-star shape: 15 us per launch of which 4 are arithmetic, VALU busy 27 %), and the two-lane
+    // form halves the chain of dependent work per wave (half the categories to score, to exponentiate and
+    // to compare per lane) at the same number of workgroups.  Same draw, bit for bit.
+    const int64_t chunks = (c->batch + 63) / 64;
+    const bool short_launch = BMM_SMALL_SPLIT && p.KT >= 16 && !alt && chunks < (int64_t)c->num_cus * 24;
+    if (c->bits && (p.KT > 32 || short_launch) && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
+        if (resample_fn f = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W)) {
+            c->fn = f;
+            c->NT = kThreadsSplit;
+            split = 2;
+        }
     }
     if (const char* dbg = alt ? nullptr : dbg_env("BMM_DEBUG_THREADS")) {
         const int nt = atoi(dbg);
@@ -1593,6 +1611,13 @@ int run_sweeps_hooked(bmm_chain* c, int nsamples, const bmm_relabel_hooks* h) {
         const bool staged = c->probs_dst && !(window && use_ring);
         c->probs_dst = nullptr;
         if (rc) return rc;
+        // progress of a run that feeds the host's relabelling: as the sweeps are enqueued (the hand-off keeps the
+        // host within a sweep of the device from the window on); the cluster count is not fetched here
+        if (g_progress.fn && g_progress.every > 0 && (j % g_progress.every == 0 || j == nsamples - 1) &&
+            g_progress.fn(g_progress.user, j + 1, nsamples, -1) != 0) {
+            (void)hipStreamSynchronize(c->stream);
+            return set_err(BMM_E_CALLBACK, "the progress hook stopped the run after sample %d", j + 1);
+        }
         if (staged) {
             HIP_TRY(hipMemcpyAsync(hbuf[j & 1], dbuf[j & 1].p, mat_bytes, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(ev[j & 1], c->stream));
