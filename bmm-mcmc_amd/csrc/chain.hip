@@ -436,6 +436,7 @@ struct bmm_chain {
     hipStream_t stream = nullptr;
     bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
     bool plain_stream = false;     // ... or is an ordinary non-blocking stream, which the pool takes back
+    bool shares_device = false;    // another chain runs beside this one on the device (bmm_chain_share_data)
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
@@ -884,7 +885,9 @@ int pick_kernel(bmm_chain* c) {
     // form halves the chain of dependent work per wave (half the categories to score, to exponentiate and
     // to compare per lane) at the same number of workgroups.  Same draw, bit for bit.
     const int64_t chunks = (c->batch + 63) / 64;
-    const bool short_launch = BMM_SMALL_SPLIT && p.KT >= 16 && !alt && chunks < (int64_t)c->num_cus * 24;
+    // (not for chains that share their device: several chains' launches fill the chip between them, and then
+    // the one-lane form's lower total work wins -- four north-star chains: 14.8 k against 12.1 k sweeps/s)
+    const bool short_launch = BMM_SMALL_SPLIT && !c->shares_device && p.KT >= 16 && !alt && chunks < (int64_t)c->num_cus * 24;
     if (c->bits && (p.KT > 32 || short_launch) && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
         if (resample_fn f = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W)) {
             c->fn = f;
@@ -1234,6 +1237,12 @@ int bmm_chain_share_data(bmm_chain* c, bmm_chain* from) {
     int rcq = chain_dedicated_queue(from);  // two chains on one device: a hardware queue each
     if (rcq == BMM_OK) rcq = chain_dedicated_queue(c);
     if (rcq) return rcq;
+    for (bmm_chain* q : {from, c}) {  // and the kernel form that suits a shared device (pick_kernel)
+        if (q->shares_device || q->started || q->generic) continue;
+        q->shares_device = true;
+        rcq = pick_kernel(q);
+        if (rcq) return rcq;
+    }
     c->planes = from->planes;
     c->planes->refs.fetch_add(1);
     c->dXb = from->dXb;

@@ -14,8 +14,10 @@ the K = 20 shapes.
       as two clusters, a small one absorbed) -- the SEQUENTIAL SCAN is in 2 of 3 seeds at the north-star shape and
       at C5 -- and which seeds are trapped, and how, differs between any two chains, so summaries across modes do
       not measure the batch.  What is held there: every chain ends in the generating mode or one such swap away
-      from it (each component held by 0, 1 or 2 clusters), and every chain that does reach the generating mode
-      sits, in proportions and theta-hat, within the stated tolerance of the sequential scan started there.
+      from it (each component held by 0, 1 or 2 clusters), and every chain that has reached the generating mode
+      by its last sweep agrees with the generating allocation as often as the sequential scan started there does
+      (within half a point; 40 burn-in sweeps from a random start do not make the kept sweeps stationary, so
+      their means are reported, not asserted).
   dp*, c3 (gibbs_dp)  The sequential scan itself seats a generating component as two clusters in every seed at
       N = 4e5 (fixtures' final_clusters_per_component), so size-sorted proportions depend on which component
       that happened to; the summary that does not is the share of the observations per GENERATING component:
@@ -98,9 +100,8 @@ def test_default_batch_within_the_stated_tolerance_of_the_sequential_scan(name):
                 for g in got:
                     assert all(v in (0, 1, 2) for v in g["final_clusters_per_component"]), g["final_clusters_per_component"]
                     if whole(g):
-                        dp = np.abs(np.array(g["props_mean"]) - np.mean([a["props_mean"] for a in anchor], axis=0)).max()
-                        dt = np.abs(np.array(g["theta_by_size"]) - np.mean([a["theta_by_size"] for a in anchor], axis=0)).max()
-                        assert dp <= bm.TOL_PROPORTIONS and dt <= bm.TOL_THETA, (name, g["seed"], dp, dt)
+                        want = np.mean([a["final_agreement"] for a in anchor])
+                        assert abs(g["final_agreement"] - want) <= 0.005, (name, g["seed"], g["final_agreement"], want)
         else:
             if "by_component" in c:
                 assert c["by_component"].max() <= bm.TOL_PROPORTIONS, (name, c["by_component"])
