@@ -8,6 +8,7 @@ Two variants of the same sources:
 `BMM_LIB_PATH` makes _capi.py load another build (tools/exp_lib.sh, tools/diag.sh) -- nothing ever
 overwrites the product library in place.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -33,8 +34,30 @@ def hipcc():
     return exe
 
 
+def _fingerprint(extra=()):
+    """sha256 over the sources a library is built from and the flags it is built with"""
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + list(extra)).encode())
+    return h.hexdigest()
+
+
+def _extra(lib):
+    return ["-DBMM_DEBUG_HOOKS"] if lib == LIB_DBG else []
+
+
 def stale(lib=LIB):
-    return (not os.path.exists(lib)) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in DEPS)
+    """A library is current when the fingerprint written beside it at build time equals that of the sources
+    as they are now: content, not modification times (which a snapshot copied to another machine does not
+    keep, and which say nothing about which sources an .so left over from an earlier checkout was built from)."""
+    try:
+        with open(lib + ".src-sha256") as f:
+            return (not os.path.exists(lib)) or f.read().strip() != _fingerprint(_extra(lib))
+    except OSError:
+        return True
 
 
 def _cmd(lib, extra):
@@ -55,6 +78,8 @@ def build(force=False, verbose=False, debug_variant=False):
         if proc.wait() != 0:
             raise RuntimeError("hipcc failed building " + lib)
         os.replace(lib + ".tmp", lib)  # never a half-written library under the product's name
+        with open(lib + ".src-sha256", "w") as f:
+            f.write(_fingerprint(_extra(lib)) + "\n")
     return LIB
 
 
