@@ -244,7 +244,9 @@ def main():
                 "dt": multi.max_over_ranks(t1 - t0), "kern_ms": kern_ms, "kern_n": lps * steps, "lps": lps,
                 "X": X, "chains": chains, "layout": ch.x_layout(), "first": first, "nchains": nchains,
                 "bcast_ms": multi.max_over_ranks(bcast_ms),
-                "rank_sweeps_per_s": multi.gather_summaries([nchains * steps / t_own])[:, 0].tolist()}
+                # collectives: every rank calls them (here, not under `if rank == 0`)
+                "rank_sweeps_per_s": multi.gather_summaries([nchains * steps / t_own])[:, 0].tolist(),
+                "ranks_seen": int(round(float(multi.gather_summaries([1.0]).sum())))}
 
     def close(m):
         for c in m["chains"][1:] + m["chains"][:1]:  # borrowers of the planes first
@@ -438,7 +440,7 @@ def main():
             "roofline": roofline_of(m, args.steps, key),
         }
         if world > 1:
-            seen = int(multi.gather_summaries([1.0]).sum())
+            seen = m["ranks_seen"]
             result["multi_gpu"] = {
                 "launcher": "torch.distributed.run: one process per GPU; the bit planes broadcast once from rank 0 "
                             "(torch.distributed.broadcast, backend %s)" % ("gloo (REHEARSAL on one device, not a measurement)"

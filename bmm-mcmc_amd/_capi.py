@@ -25,7 +25,7 @@ SYMBOLS = [
     "bmm_device_count", "bmm_collapsed_run_probs", "bmm_dp_run_probs", "bmm_sb_run_probs", "bmm_full_run_probs",
     "bmm_multi_run", "bmm_multi_selfcheck", "bmm_chains_sweeps", "bmm_chain_share_data", "bmm_chain_planes",
     "bmm_chain_planes_filled", "bmm_chain_shard_resample_async", "bmm_chain_stream",
-    "bmm_chains_broadcast_planes", "bmm_set_progress", "bmm_last_run_phases", "bmm_host_threads", "bmm_multi_plan",
+    "bmm_chains_broadcast_planes", "bmm_set_progress", "bmm_last_run_phases", "bmm_host_threads", "bmm_multi_plan", "bmm_release_pools",
 ]
 
 

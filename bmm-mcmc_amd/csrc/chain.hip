@@ -996,6 +996,26 @@ int bmm_last_run_phases(double* ms) {
 }
 int bmm_host_threads(void) { return host_threads(); }
 
+// what the library keeps between calls -- up to eight 4 MiB pieces of pinned staging and up to four idle plain
+// streams per device -- released now (a long-lived host process that is done sampling)
+int bmm_release_pools(void) {
+    {
+        StagePool& sp = stage_pool();
+        std::vector<void*> idle;
+        { std::lock_guard<std::mutex> g(sp.m); idle.swap(sp.idle); }
+        for (void* p : idle) (void)hipHostFree(p);
+    }
+    StreamPool& st = stream_pool();
+    for (int d = 0; d < 64; ++d) {
+        std::vector<hipStream_t> idle;
+        { std::lock_guard<std::mutex> g(st.m); idle.swap(st.idle[d]); }
+        if (idle.empty()) continue;
+        if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (hipStream_t s : idle) (void)hipStreamDestroy(s);
+    }
+    return BMM_OK;
+}
+
 int bmm_device_count(int* n) {
     int k = 0;
     hipError_t e = hipGetDeviceCount(&k);

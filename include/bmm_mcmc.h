@@ -42,7 +42,15 @@
  * of the batch-1 chain over 6 seeds (measured 0.038; noise-limited -- an unbounded-K chain wanders,
  * seed s.d. 0.08).
  * tests/test_gpu_tolerance.py holds the HIP path to all of it on the GPU, default batch against the
- * batch-1 oracle chain.  The stick-breaking and full samplers have no batch and no tolerance:
+ * batch-1 oracle chain.  At the shapes the benchmark numbers are quoted on the batch-1 chain is a committed
+ * fixture (tests/golden/tolerance_*.json: K = 20 with N = 1e6, P = 50 and N = 1e7, P = 100; K = 3, N = 1e5; five
+ * DP shapes up to N = 1e6) and tests/test_gpu_tolerance_fixtures.py holds the default batch to the same two
+ * numbers against it, per component including the 1/210 one: measured 5e-6 and 1.2e-4 from the generating
+ * allocation (the bias of a batch shrinks with N; the bundled N <= 1000 sets above are the hard case).  For the
+ * DP sampler there the quantity is the share of the observations per generating component (the sequential
+ * scan itself seats a generating component as two clusters at N >= 1e5).  The default batch is exactly
+ * floor(N/8) (floor(N/16) DP): the ratios at which all of this is measured.
+ * The stick-breaking and full samplers have no batch and no tolerance:
  * their z-step is exactly parallel (src/stickbreaking.cpp:69-92 reads only sweep j-1).
  */
 #ifndef BMM_MCMC_H
@@ -105,6 +113,11 @@ int bmm_set_progress(bmm_progress_fn fn, void* user, int every);
 int bmm_last_run_phases(double* ms /* BMM_RUN_PHASES doubles */);
 /* host threads the two ends of a run use (affinity mask, cgroup CPU quota, at most 16) */
 int bmm_host_threads(void);
+/* Between calls the library keeps up to eight 4 MiB pieces of pinned host staging and up to four idle plain
+ * streams per device (creating and destroying a stream costs about 2 ms each on this runtime, pinning 4 MiB
+ * about 1 ms: a fifth of what a 220-sweep drop-in call at N = 1e6 spends outside its sweeps).  This releases
+ * them; they come back with the next call. */
+int bmm_release_pools(void);
 
 /* ---- drop-in entry points --------------------------------------------------------
  * Replaces collapsed_gibbs_cpp (src/collapsed_gibbs.cpp:24-36; .Call symbol

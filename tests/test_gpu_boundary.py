@@ -67,6 +67,16 @@ def test_progress_hook_can_stop_the_run():
     assert bm.gibbs_collapsed(X, 4, 2, burnin=1, seed=1)["z"].shape == (3, 2000)   # and the library lives on
 
 
+def test_pools_can_be_released_and_come_back(oracle):
+    X, _, _, _ = synth(4000, 10, 3, 2)
+    z0 = _z0(4000, 3, 5)
+    want = oracle.collapsed(X, z0, 6, 3, 0.0, 0.5, 0.5, 1, 1, 1, seed=2, batch=500)
+    for _ in range(3):
+        got = bm.gibbs_collapsed(X, 6, 3, burnin=1, seed=2, batch=500, initial_K=z0)
+        assert np.array_equal(got["z"], want["z"])
+        assert _capi.lib().bmm_release_pools() == 0      # pinned staging and idle streams go; the next call re-makes them
+
+
 def test_run_phases_and_host_threads_are_reported():
     X, _, _, _ = synth(50000, 40, 4, 2)
     bm.gibbs_collapsed(X, 30, 4, burnin=10, seed=2)

@@ -156,3 +156,36 @@ def test_set_data_device_waits_for_the_producer(oracle):
     Xh = Xt.cpu().numpy().T
     assert np.array_equal(nk, np.bincount(z0 - 1, minlength=K))
     assert np.array_equal(s, np.stack([Xh[z0 == k + 1].sum(axis=0) for k in range(K)]))
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_of_a_two_rank_job_rehearsed_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed with two
+    ranks on the one device there is (BMM_BENCH_REHEARSE=1: gloo instead of RCCL -- the code path, never a
+    measurement): plane broadcast, per-rank seeds, collectives called by every rank, max over ranks, ONE JSON
+    line from rank 0 with the multi_gpu block a scaling record can be checked against."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BMM_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--warmup", "2", "--burn", "4", "--workload", "c2", "--no-cpu"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
+    m = d["multi_gpu"]
+    assert m["ranks_seen_by_the_collective"] == 2 and m["world_size"] == 2 and len(m["per_rank_sweeps_per_s"]) == 2
+    assert "REHEARSAL" in m["launcher"] and m["plane_bytes"] == 4 * 100_000
+    assert d["config"]["chains"] == 2 and d["value"] > 0
+    assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]    # value = chains x steps / max time
