@@ -559,7 +559,9 @@ def bench_native(args):
     X, _ = synth.device_matrix(N, P, K_true, dseed, torch.device("cuda", 0))
     chains[0].set_data_device(X.data_ptr())
     del X
+    t_b = time.perf_counter()
     bm.broadcast_planes(chains)
+    bcast_ms = 1e3 * (time.perf_counter() - t_b)
     for c, ch in enumerate(chains):
         rng = np.random.default_rng(1000 + c)
         if sampler == "collapsed":
@@ -582,7 +584,9 @@ def bench_native(args):
         "config": {"workload": "%s: gibbs_%s K=%d N=%d P=%d, 1 chain per GPU" % (args.workload, sampler, K, N, P),
                    "sampler": sampler, "K": K, "N": N, "P": P, "batch": chains[0].batch, "chains": n,
                    "launcher": "native: one process, one host thread per GPU, RCCL broadcast of the bit planes "
-                               "inside the library (bmm_chains_broadcast_planes)"}}))
+                               "inside the library (bmm_chains_broadcast_planes)"},
+        "multi_gpu": {"launcher": "native (bmm_chains_broadcast_planes: ncclCommInitAll + one ncclBroadcast; bmm_chains_sweeps)",
+                      "devices": n, "plane_broadcast_ms": bcast_ms, "plane_bytes": 4 * ((P + 31) // 32) * N}}))
     for ch in chains:
         ch.close()
 
