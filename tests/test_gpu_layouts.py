@@ -118,3 +118,38 @@ def test_wide_category_counts_two_lanes_per_observation(oracle, dbg_lib, nosplit
     want = oracle.full(X, pi0, th0, 5, 40, 0.0, 0.5, 0.5, 1, 1, 0, seed=6)
     for k in ("z", "theta", "alpha", "pi"):
         assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("nosplit", [False, True])
+def test_both_forms_of_16_to_32_accumulators_on_short_launches(oracle, dbg_lib, nosplit):
+    """Launches of at most 24 chunks per CU run 16-32 accumulators two lanes per observation (pick_kernel); the
+    one-lane form of the same kernels is what long launches (C5) run.  Test-sized inputs are all short launches,
+    so the one-lane form is reached here through BMM_DEBUG_NOSPLIT: both must be the oracle's chain, bit for bit."""
+    if nosplit:
+        dbg_lib.setenv("BMM_DEBUG_NOSPLIT", "1")
+    else:
+        dbg_lib.delenv("BMM_DEBUG_NOSPLIT", raising=False)
+    for N, P, K, batch in [(3000, 100, 20, 400), (2500, 50, 16, 2500), (1999, 33, 24, 97), (1200, 64, 28, 300), (2100, 20, 32, 777)]:
+        X, _, _, _ = synth(N, P, 4, K + P)
+        z0 = _z0(N, K, 3)
+        got = bm.gibbs_collapsed(X, 5, K, burnin=0, seed=5, batch=batch, initial_K=z0)
+        want = oracle.collapsed(X, z0, 5, K, 0.0, 0.5, 0.5, 1, 1, 0, seed=5, batch=batch)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, N, P, K)
+    X, _, _, _ = synth(3000, 50, 6, 19)
+    got = bm.gibbs_dp(X, 8, burnin=0, maxK=30, seed=31, batch=187)          # the c3 shape's 32 accumulators
+    want = oracle.dp(X, 8, 0.0, 0.5, 0.5, 1, 1, 0, 30, seed=31, batch=187)
+    for k in ("z", "theta", "alpha"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    rng = np.random.default_rng(4)
+    pi0 = rng.dirichlet(np.ones(24))
+    th0 = 0.05 + 0.9 * rng.random((24, 40))
+    X, _, _, _ = synth(2500, 40, 3, 2)
+    got = bm.gibbs_stickbreaking(X, 5, 24, burnin=0, seed=6, initial_pi=pi0, initial_theta=th0)
+    want = oracle.stickbreaking(X, pi0, th0, 5, 24, 0.0, 0.5, 0.5, 1, 1, 0, seed=6)
+    for k in ("z", "theta", "alpha", "pi"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    # and the kernel really differs: 1024 threads with two lanes per observation, the default size otherwise
+    with bm.Chain("collapsed", 3000, 100, 20, seed=1, batch=400) as ch:
+        shape = ch.kernel_shape()
+    assert shape["threads"] == (1024 if not nosplit else shape["threads"])
