@@ -181,15 +181,20 @@ uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b
 struct AsyncPack {
     std::unique_ptr<uint32_t[]> words;
     std::atomic<uint32_t> seen{0};
+    std::atomic<int> failed{0};  // the workers could not be started (no exception may leave a thread)
     std::thread th;
     void start(const int32_t* X, int64_t N, int P) {
         const int W = (P + 31) / 32;
         words.reset(new uint32_t[(size_t)W * (size_t)N]);
         uint32_t* const out = words.get();
         th = std::thread([this, X, N, P, out]() {
-            parallel_ranges(N, 32768, 64, [&](int64_t lo, int64_t hi) {
-                seen.fetch_or(pack_rows_host(X, N, P, lo, hi, out, N, 0), std::memory_order_relaxed);
-            });
+            try {
+                parallel_ranges(N, 32768, 64, [&](int64_t lo, int64_t hi) {
+                    seen.fetch_or(pack_rows_host(X, N, P, lo, hi, out, N, 0), std::memory_order_relaxed);
+                });
+            } catch (...) {
+                failed.store(1);
+            }
         });
     }
     bool running() const { return th.joinable(); }
@@ -1854,8 +1859,7 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int
             if (rc == BMM_OK) rc = run_start_state(c, io);
             if (rc) return rc;
             clock.lap(1);
-            if (host_pack && c->bits) {
-                pack.join();
+            if (host_pack && c->bits && (pack.join(), pack.failed.load() == 0)) {
                 if (pack.seen.load() & ~1u) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
                 rc = chain_set_planes_host(c, pack.words.get());
                 pack.words.reset();
