@@ -228,6 +228,49 @@ struct StagePool {
     }
 };
 StagePool& stage_pool() { static StagePool* const pool = new StagePool(); return *pool; }
+
+// Device memory of a finished call, kept for the next one: a chain's arena, a run's arena and the bit planes
+// come from here.  hipMalloc is usually free on this runtime (0.02 ms) but now and then takes 10 ms and more
+// when the driver has to map fresh memory (a 220-sweep call at N = 1e6 lasts 37 ms in all), and hipFree costs
+// 0.2 ms a piece.  Per device at most six idle blocks and 512 MiB in all are kept; a request takes the smallest
+// idle block that fits and is at most twice as large.  bmm_release_pools frees them.
+struct DevPool {
+    struct Block { void* p; size_t bytes; };
+    std::mutex m;
+    std::vector<Block> idle[64];
+    static constexpr size_t kMaxIdleBytes = (size_t)512 << 20;
+    void* get(int device, size_t bytes, size_t* got) {
+        if (device >= 0 && device < 64) {
+            std::lock_guard<std::mutex> g(m);
+            std::vector<Block>& v = idle[device];
+            int best = -1;
+            for (int i = 0; i < (int)v.size(); ++i)
+                if (v[(size_t)i].bytes >= bytes && v[(size_t)i].bytes <= 2 * bytes + 4096 && (best < 0 || v[(size_t)i].bytes < v[(size_t)best].bytes)) best = i;
+            if (best >= 0) {
+                const Block b = v[(size_t)best];
+                v.erase(v.begin() + best);
+                *got = b.bytes;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;  // the caller reports hipGetLastError
+        *got = bytes;
+        return p;
+    }
+    void put(int device, void* p, size_t bytes) {
+        if (!p) return;
+        if (device >= 0 && device < 64) {
+            std::lock_guard<std::mutex> g(m);
+            std::vector<Block>& v = idle[device];
+            size_t held = 0;
+            for (const Block& b : v) held += b.bytes;
+            if (v.size() < 6 && held + bytes <= kMaxIdleBytes) { v.push_back(Block{p, bytes}); return; }
+        }
+        (void)hipFree(p);
+    }
+};
+DevPool& dev_pool() { static DevPool* const pool = new DevPool(); return *pool; }
 struct Stage {  // one piece, back to the pool on every return path
     void* p = stage_pool().get();
     ~Stage() { stage_pool().put(p); }
@@ -465,7 +508,7 @@ struct bmm_chain {
     uint32_t* dXb = nullptr;      // bit planes of X (k_pack_bits), what the resident kernels stream by default
     // the planes are shared by reference count between the chains of a device that run over the same data
     // (bmm_chain_share_data): the last chain to go frees them, in whatever order chains are destroyed
-    struct Planes { uint32_t* d = nullptr; std::atomic<int> refs{1}; };
+    struct Planes { uint32_t* d = nullptr; size_t bytes = 0; std::atomic<int> refs{1}; };
     Planes* planes = nullptr;
     bool xb_borrowed = false;     // this chain took its planes from another one
     bool bits = false;
@@ -473,6 +516,7 @@ struct bmm_chain {
     // the chain's fixed state is carved out of one allocation (arena), the buffers of a *_run call out of a
     // second one (run_arena): a malloc / free pair per buffer cost the drop-in call more than a millisecond
     char *arena = nullptr, *run_arena = nullptr;
+    size_t arena_bytes = 0, run_arena_bytes = 0;  // as handed out by the device pool
     int32_t* dZ[2] = {nullptr, nullptr};
     int32_t *dNk = nullptr, *dS = nullptr, *dDNk = nullptr, *dDS = nullptr;
     double *dAlpha = nullptr, *dTab = nullptr, *dPi = nullptr, *dTheta = nullptr;
@@ -500,11 +544,13 @@ struct bmm_chain {
 namespace {
 
 int planes_alloc(bmm_chain* c, size_t words) {
-    uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc(&d, words * sizeof(uint32_t)));
+    size_t got = 0;
+    uint32_t* d = static_cast<uint32_t*>(dev_pool().get(c->device, words * sizeof(uint32_t), &got));
+    if (!d) return set_err(BMM_E_HIP, "allocating the bit planes failed: %s", hipGetErrorString(hipGetLastError()));
     c->planes = new (std::nothrow) bmm_chain::Planes();
-    if (!c->planes) { (void)hipFree(d); return set_err(BMM_E_ARG, "out of host memory"); }
+    if (!c->planes) { dev_pool().put(c->device, d, got); return set_err(BMM_E_ARG, "out of host memory"); }
     c->planes->d = d;
+    c->planes->bytes = got;
     c->dXb = d;
     return BMM_OK;
 }
@@ -710,7 +756,8 @@ int chain_alloc(bmm_chain* c) {
     };
     Carver measure{nullptr};
     carve(measure);
-    HIP_TRY(hipMalloc(&c->arena, measure.used));
+    c->arena = static_cast<char*>(dev_pool().get(c->device, measure.used, &c->arena_bytes));
+    if (!c->arena) return set_err(BMM_E_HIP, "allocating the chain's state failed: %s", hipGetErrorString(hipGetLastError()));
     Carver real{c->arena};
     const size_t zeroed = carve(real);
     if (c->generic) HIP_TRY(hipMalloc(&c->dScratch, (size_t)c->scratch_stride * p.Kc * sizeof(double)));
@@ -1001,8 +1048,9 @@ int bmm_last_run_phases(double* ms) {
 }
 int bmm_host_threads(void) { return host_threads(); }
 
-// what the library keeps between calls -- up to eight 4 MiB pieces of pinned staging and up to four idle plain
-// streams per device -- released now (a long-lived host process that is done sampling)
+// what the library keeps between calls -- up to eight 4 MiB pieces of pinned staging, and per device up to four
+// idle plain streams and up to 512 MiB of device blocks -- released now (a long-lived host process that is done
+// sampling)
 int bmm_release_pools(void) {
     {
         StagePool& sp = stage_pool();
@@ -1011,12 +1059,16 @@ int bmm_release_pools(void) {
         for (void* p : idle) (void)hipHostFree(p);
     }
     StreamPool& st = stream_pool();
+    DevPool& dp = dev_pool();
     for (int d = 0; d < 64; ++d) {
         std::vector<hipStream_t> idle;
+        std::vector<DevPool::Block> blocks;
         { std::lock_guard<std::mutex> g(st.m); idle.swap(st.idle[d]); }
-        if (idle.empty()) continue;
+        { std::lock_guard<std::mutex> g(dp.m); blocks.swap(dp.idle[d]); }
+        if (idle.empty() && blocks.empty()) continue;
         if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
         for (hipStream_t s : idle) (void)hipStreamDestroy(s);
+        for (const DevPool::Block& b : blocks) (void)hipFree(b.p);
     }
     return BMM_OK;
 }
@@ -1124,10 +1176,12 @@ void bmm_chain_destroy(bmm_chain* c) {
 #endif
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->planes && c->planes->refs.fetch_sub(1) == 1) {  // the last chain over these planes
-        (void)hipFree(c->planes->d);
+        dev_pool().put(c->device, c->planes->d, c->planes->bytes);
         delete c->planes;
     }
-    void* bufs[] = {c->dX_owned, c->arena, c->run_arena, c->dScratch, c->dProbs, c->dWts, c->dWtot};
+    dev_pool().put(c->device, c->arena, c->arena_bytes);  // the stream is idle (synchronised above)
+    dev_pool().put(c->device, c->run_arena, c->run_arena_bytes);
+    void* bufs[] = {c->dX_owned, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     chain_stream_release(c->device, c->stream, c->plain_stream);  // synchronised above
@@ -1582,7 +1636,8 @@ int run_prepare(bmm_chain* c, int nsamples, int burnin) {
     };
     Carver measure{nullptr};
     carve(measure);
-    HIP_TRY(hipMalloc(&c->run_arena, measure.used));
+    c->run_arena = static_cast<char*>(dev_pool().get(c->device, measure.used, &c->run_arena_bytes));
+    if (!c->run_arena) return set_err(BMM_E_HIP, "allocating the run's buffers failed: %s", hipGetErrorString(hipGetLastError()));
     Carver real{c->run_arena};
     carve(real);
     return BMM_OK;

@@ -113,10 +113,11 @@ int bmm_set_progress(bmm_progress_fn fn, void* user, int every);
 int bmm_last_run_phases(double* ms /* BMM_RUN_PHASES doubles */);
 /* host threads the two ends of a run use (affinity mask, cgroup CPU quota, at most 16) */
 int bmm_host_threads(void);
-/* Between calls the library keeps up to eight 4 MiB pieces of pinned host staging and up to four idle plain
- * streams per device (creating and destroying a stream costs about 2 ms each on this runtime, pinning 4 MiB
- * about 1 ms: a fifth of what a 220-sweep drop-in call at N = 1e6 spends outside its sweeps).  This releases
- * them; they come back with the next call. */
+/* Between calls the library keeps up to eight 4 MiB pieces of pinned host staging and, per device, up to four
+ * idle plain streams and up to six device blocks of at most 512 MiB in all (creating and destroying a stream
+ * costs about 2 ms each on this runtime, pinning 4 MiB about 1 ms, and a device allocation now and then 10 ms:
+ * together more than a 220-sweep drop-in call at N = 1e6 spends outside its sweeps).  This releases them; they
+ * come back with the next call. */
 int bmm_release_pools(void);
 
 /* ---- drop-in entry points --------------------------------------------------------
