@@ -321,6 +321,9 @@ constexpr int kThreadsLarge = 512;   // 256 VGPRs
 #ifndef BMM_SMALL_SPLIT
 #define BMM_SMALL_SPLIT 1  // short launches of 16-32 accumulators run two lanes per observation (pick_kernel)
 #endif
+#ifndef BMM_SELF_TABLES
+#define BMM_SELF_TABLES 1  // small finite-sampler shapes: resample workgroups build their own tables (pick_kernel)
+#endif
 constexpr int kStageWide = BMM_STAGE_WIDE;  // features in flight per wave where registers allow
 
 int pick_kt(int cats) {
@@ -471,6 +474,15 @@ resample_fn resample_kernel_w(int kt, int minus, bool bits) {
 resample_fn resample_kernel(int kt, int minus, bool bits, int gw) {
     return gw == kGroupW ? resample_kernel_w<kGroupW>(kt, minus, bits) : resample_kernel_w<kGroupWAlt>(kt, minus, bits);
 }
+// SELF: 256-thread workgroups that build their own table image (finite sampler, small shapes: kernels.hip.h)
+resample_fn resample_kernel_self(int kt) {
+    switch (kt) {
+        case 4: return k_resample<4, 256, 1, 16, true, 1, false, kGroupW, true>;
+        case 8: return k_resample<8, 256, 1, 16, true, 1, false, kGroupW, true>;
+        case 12: return k_resample<12, 256, 1, 16, true, 1, false, kGroupW, true>;
+    }
+    return nullptr;
+}
 resample_fn resample_kernel_small_of(int kt, int minus, bool bits) {
     if (bits) return minus == 0 ? resample_kernel_small<0, true>(kt) : resample_kernel_small<1, true>(kt);
     return minus == 0 ? resample_kernel_small<0, false>(kt) : resample_kernel_small<1, false>(kt);
@@ -485,6 +497,8 @@ struct bmm_chain {
     bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
     bool plain_stream = false;     // ... or is an ordinary non-blocking stream, which the pool takes back
     bool shares_device = false;    // another chain runs beside this one on the device (bmm_chain_share_data)
+    bool self_tables = false;      // the resample workgroups build their own table image: no k_count_tables per batch
+    size_t lds_bytes_base = 0;     // lds_bytes without the SELF kernels' scratch
     int64_t batch = 1;
     double alpha0 = 1.0;
     int NT = 0, grid_max = 0, minus_in_lds = 1;
@@ -786,6 +800,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
     a.dbg_flag = c->dDbgFlag; a.dbg_inject = dbg_env("BMM_DEBUG_BADLABEL") != nullptr;
+    a.Nk = c->dNk; a.S = c->dS; a.alpha_ptr = c->dAlpha;
     const bool emit = c->probs_dst != nullptr;
     const bool use_generic = c->generic || (emit && !c->fn_emit);  // the int32 layout has no emitting twin
     const int OT = emit ? c->NT_emit : c->OT, gmax = emit ? c->grid_max_emit : c->grid_max;
@@ -819,8 +834,9 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     } else {
         const resample_fn fn = emit ? c->fn_emit : c->fn;
         const int nt = emit ? c->NT_emit : c->NT;
-        if (e0) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(nt), (uint32_t)c->lds_bytes, c->stream, e0, e1, 0, c->p, a);
-        else hipLaunchKernelGGL(fn, dim3(grid), dim3(nt), c->lds_bytes, c->stream, c->p, a);
+        const size_t lds = emit ? c->lds_bytes_base : c->lds_bytes;  // the SELF kernels carry scratch behind the image
+        if (e0) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(nt), (uint32_t)lds, c->stream, e0, e1, 0, c->p, a);
+        else hipLaunchKernelGGL(fn, dim3(grid), dim3(nt), lds, c->stream, c->p, a);
     }
     HIP_TRY(hipGetLastError());
     if (emit) {  // before the next k_count_tables rewrites the image's cluster sizes
@@ -839,10 +855,10 @@ int probs_alloc(bmm_chain* c, bool with_matrix) {
         const int minus = explicit_params(c->p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
         c->fn_emit = resample_kernel_emit(c->p.KT, minus, c->p.W);
         c->NT_emit = threads_for(c->p.KT, true);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes_base);
         int pe = 0;
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pe, reinterpret_cast<const void*>(c->fn_emit), c->NT_emit, c->lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pe, reinterpret_cast<const void*>(c->fn_emit), c->NT_emit, c->lds_bytes_base);
         if (e != hipSuccess) { c->fn_emit = nullptr; return set_err(BMM_E_HIP, "kernel set-up failed: %s", hipGetErrorString(e)); }
         c->grid_max_emit = (pe < 1 ? 1 : pe) * c->num_cus;
     }
@@ -910,7 +926,9 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
             if (dbl < len) len = dbl;
         }
         const int64_t hi = lo + len > p.N ? p.N : lo + len;
-        int rc = launch_count_tables(c);
+        // (SELF kernels build their own image from S + the pending deltas; a sweep that hands its probabilities
+        // to the host runs the emitting twin, which reads the image k_count_tables writes)
+        int rc = c->self_tables && !c->probs_dst ? BMM_OK : launch_count_tables(c);
         if (rc) return rc;
         rc = launch_resample(c, zin, zout, lo, hi, (uint32_t)j);
         if (rc) return rc;
@@ -928,6 +946,8 @@ int pick_kernel(bmm_chain* c) {
     const size_t lds_max = kLdsMax;
     const int minus = explicit_params(p.mode) ? 0 : (c->minus_in_lds ? 1 : 2);
     c->NT = threads_for(p.KT, c->bits);
+    c->lds_bytes = c->lds_bytes_base;  // (a previous choice may have been a SELF kernel, which carries scratch)
+    c->self_tables = false;
     const bool alt = p.W != kGroupW;  // the narrower groups: default-sized kernels only
     c->fn = resample_kernel(p.KT, minus, c->bits, p.W);
     int split = 1;
@@ -978,6 +998,20 @@ int pick_kernel(bmm_chain* c) {
         int pc2 = 0;
         if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(f), 256, c->lds_bytes);
         if (e2 == hipSuccess && pc2 >= 1) { c->fn = f; c->NT = 256; c->OT = 256; c->grid_max = pc2 * c->num_cus; }
+    }
+    // ... and such workgroups build the table image themselves when that is at most two logs per thread: the
+    // shape is bound by launches then, and this drops k_count_tables from every batch (BASELINE config 2)
+    if (BMM_SELF_TABLES && c->NT == 256 && split == 1 && c->bits && !alt && minus == 1 && !c->shares_device &&
+        self_tables_fit(p.mode, p.K, p.P, 256) && !dbg_env("BMM_DEBUG_NOSELF")) {
+        if (resample_fn f = resample_kernel_self(p.KT)) {
+            const size_t lds = (c->lds_bytes_base + 7) / 8 * 8 + self_scratch_doubles(p.K, p.KT, p.P) * sizeof(double);
+            hipError_t e3 = lds <= lds_max ? hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                           : hipErrorInvalidValue;
+            int pc3 = 0;
+            if (e3 == hipSuccess) e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc3, reinterpret_cast<const void*>(f), 256, lds);
+            if (e3 == hipSuccess && pc3 >= 1) { c->fn = f; c->lds_bytes = lds; c->grid_max = pc3 * c->num_cus; c->self_tables = true; }
+            else (void)hipGetLastError();
+        }
     }
     return BMM_OK;
 }
@@ -1131,6 +1165,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
             c->lds_bytes = (size_t)layout_of(c).head() * sizeof(double) + hist_bytes;
         }
         if (c->lds_bytes > lds_max) c->generic = true;  // third tier: nothing resident
+        c->lds_bytes_base = c->lds_bytes;
     }
     if (c->generic) {
         // any shape: tables gathered from global memory, scores in a scratch column per thread

@@ -470,6 +470,10 @@ struct ResampleArgs {
     unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
     int* dbg_flag;         // -DBMM_DEBUG_HOOKS builds: set when a kernel meets a label outside its range
     int dbg_inject;        //   ... and a test's way to make one (BMM_DEBUG_BADLABEL)
+    // SELF kernels (workgroups that build their own table image): the folded statistics and the concentration
+    const int32_t* Nk;
+    const int32_t* S;
+    const double* alpha_ptr;
 };
 
 // The test variant of the library (-DBMM_DEBUG_HOOKS) checks every label a resample kernel is about to count
@@ -742,11 +746,121 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #define BMM_LOOKUP_PRIO 2
 #endif
 
+// SELF: k_count_tables' work done by every resample workgroup for itself, straight into its LDS image -- for the
+// finite sampler on shapes so small that the whole table build is at most two logs per thread (K (4P + 5) <= 2 NT:
+// BASELINE config 2, K = 3, P = 20, is 255 logs: one per thread of a 256-thread workgroup; each further round of
+// logs costs a launch about 2 us, and from the third on the table launch it replaces was cheaper).  Such shapes are bound by launches, not by work: a sweep of config 2
+// is 8 table launches + 8 resample launches + 1, each a few microseconds, and this form drops the 8 table launches
+// (every workgroup of a launch building the image of a bigger shape itself was measured in round 2: 8 000 logs per
+// workgroup cost six times what the launch did).  The statistics are not folded between batches then: a workgroup
+// reads S + the pending deltas; k_count_sweep_end folds at the end of the sweep as before.  Same functions, same
+// operands, same order as k_count_tables and write_group_tables: the image is bit-identical.
+// scratch (LDS, doubles): terms [K][4][P] (x=1 / x=0 against the full statistics, then with the scored
+// observation removed), logs [K][8], consts [KT][2] (Cp, Cm).
+__host__ __device__ inline size_t self_scratch_doubles(int K, int KT, int P) { return (size_t)K * 4 * P + (size_t)K * 8 + (size_t)KT * 2; }
+__host__ __device__ inline bool self_tables_fit(int mode, int K, int P, int threads) {
+    return mode == MODE_COLLAPSED && P <= kChunkP && (long)K * (4 * P + 5) <= 2L * threads;
+}
+template <int KT, int NT, int GW>
+__device__ __forceinline__ void build_tables_self(const ChainParams& p, const ResampleArgs& a, const TableLayout& L,
+                                                  double* lds, double* scratch, int tid) {
+    constexpr int GM = 1 << GW;
+    const int K = p.K, P = p.P;
+    const size_t KP = (size_t)K * P;
+    double* const terms = scratch;
+    double* const logs = scratch + (size_t)K * 4 * P;
+    double* const consts = logs + (size_t)K * 8;
+    const double alpha = *a.alpha_ptr;
+    const double bg = p.beta + p.gamma;
+    const double ak = div_(alpha, (double)K);
+    const int nterm = K * 4 * P, nitem = nterm + K * 5;
+    // phase A: every raw log, at most two per thread, held in registers across the barrier
+    constexpr int R = 2;
+    double raw[R];
+    bool have[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int t = tid + q * NT;
+        raw[q] = 0.0; have[q] = false;
+        if (t < nterm) {
+            const int k = t / (4 * P), role = (t / P) & 3, d = t % P;
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
+            const int32_t sd = a.S[(size_t)k * P + d] + delta_take(a.dS, (size_t)k * P + d, KP);
+            // term_x1 / term_x0 of bmm_spec.h as k_count_tables evaluates them, the denominator subtracted below
+            if (role == 0) { have[q] = n > 0; raw[q] = have[q] ? log_(p.beta + (double)sd) : 0.0; }
+            else if (role == 1) { have[q] = n > 0; raw[q] = have[q] ? log_((p.gamma + (double)n) - (double)sd) : 0.0; }
+            else if (role == 2) { have[q] = n > 1 && sd >= 1; raw[q] = have[q] ? log_(p.beta + (double)((int64_t)sd - 1)) : 0.0; }
+            else { have[q] = n > 1 && sd <= n - 1; raw[q] = have[q] ? log_((p.gamma + (double)(n - 1)) - (double)sd) : 0.0; }
+        } else if (t < nitem) {
+            const int k = (t - nterm) / 5, lane = (t - nterm) % 5;
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
+            double arg = 1.0;
+            bool need = false;
+            switch (lane) {  // the logs of k_count_tables' ninth wave, lanes 0-4 (5-7 belong to the DP's new cluster)
+                case 0: arg = bg + (double)n; need = n > 0; break;
+                case 1: arg = bg + (double)(n - 1); need = n > 1; break;
+                case 2: arg = (double)n + ak; need = n > 0; break;
+                case 3: arg = (double)(n - 1) + ak; need = n > 1; break;
+                case 4: arg = (double)(p.Ntot - 1) + alpha; need = true; break;
+                default: break;
+            }
+            logs[(size_t)k * 8 + lane] = need ? log_(arg) : 0.0;
+        }
+    }
+    __syncthreads();
+    // phase B: the terms (denominator subtracted), the constants, the cluster sizes
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int t = tid + q * NT;
+        if (t < nterm) {
+            const int k = t / (4 * P), role = (t / P) & 3;
+            terms[t] = have[q] ? raw[q] - logs[(size_t)k * 8 + (role < 2 ? 0 : 1)] : 0.0;
+        }
+    }
+    for (int k = tid; k < KT; k += NT) {
+        double cp = neg_inf(), cm = neg_inf();
+        int32_t n32 = 0;
+        if (k < K) {
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
+            const double* v = logs + (size_t)k * 8;
+            if (n > 0) cp = v[2] - v[4];
+            if (n > 1) cm = v[3] - v[4];
+            n32 = (int32_t)n;
+        }
+        consts[2 * k] = cp; consts[2 * k + 1] = cm;
+        lds[L.cp() + k] = cp;
+        lds[L.cm() + k] = cm;
+        reinterpret_cast<int32_t*>(lds + L.nk())[k] = n32;
+    }
+    __syncthreads();
+    // phase C: the group tables, laid out as write_group_tables lays them out (constant folded into group 0;
+    // accumulators past K score -inf; the own-cluster tables padded with zero groups)
+    for (int idx = tid; idx < L.G * KT * GM; idx += NT) {
+        const int g = idx / (KT * GM), k = (idx / GM) % KT;
+        const unsigned m = idx % GM;
+        const double t = k < K ? group_entry(terms + (size_t)(k * 4 + 0) * P, terms + (size_t)(k * 4 + 1) * P, g, P, m, GW) : 0.0;
+        lds[L.tp() + ((size_t)g * KT + k) * GM + m] = g == 0 ? consts[2 * k] + t : t;
+    }
+    const int gm_used = (P + kGroupWm - 1) / kGroupWm;
+    for (int idx = tid; idx < L.gm_pad() * KT * kGroupMm; idx += NT) {
+        const int g = idx / (KT * kGroupMm), k = (idx / kGroupMm) % KT;
+        const unsigned m = idx % kGroupMm;
+        double v = 0.0;
+        if (g < gm_used) {
+            const double t = k < K ? group_entry(terms + (size_t)(k * 4 + 2) * P, terms + (size_t)(k * 4 + 3) * P, g, P, m, kGroupWm) : 0.0;
+            v = g == 0 ? consts[2 * k + 1] + t : t;
+        }
+        lds[L.tm() + ((size_t)g * KT + k) * kGroupMm + m] = v;
+    }
+    for (int i = tid; i < 256; i += NT) lds[L.et() + i] = exp256_table()[i];
+}
+
 // EMIT: the launch also writes the draw's weights and their total (a.wts, a.wtot) for the probability
 // hand-off to the host's relabelling; a twin instantiation, so that the plain kernel carries no branch.
 // GW: features per lookup group of the tables (the shape's width, ChainParams::W).
-template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false, int GW = kGroupW>
+template <int KT, int NT, int MINUS, int STG, bool BITS = false, int SPLIT = 1, bool EMIT = false, int GW = kGroupW, bool SELF = false>
 __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) {
+    static_assert(!SELF || (MINUS == 1 && BITS && SPLIT == 1 && !EMIT), "self-built tables: the finite sampler's plain bit-plane kernel");
     constexpr int GM = 1 << GW;  // entries per group table
     // Bit planes, one lane per observation: a wave runs its scoring loop at raised priority.  Scoring is
     // bound by the CU's LDS pipe, the draw by the SIMD's VALU; with only four waves per SIMD the VALU
@@ -818,7 +932,11 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         if (BITS) load_words(a.Xb, p.N, W, pos.ic, b0, b1, b2, b3);
         else issue_stage<STG>(pos, p.N, P, 0, st);
     }
-    {
+    if (SELF) {
+        // behind the histogram (and its chunk counter), on an 8-byte boundary
+        double* const scratch = lds + lds_doubles + ((size_t)(K * P + K + 4) * sizeof(int32_t) + 7) / 8;
+        build_tables_self<KT, NT, GW>(p, a, L, lds, scratch, tid);
+    } else {
         // stage the table image: eight 16-byte loads in flight per lane (one L2 round trip per
         // eight, not per one)
         const double2* src = reinterpret_cast<const double2*>(a.tab);
