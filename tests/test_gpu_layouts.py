@@ -153,3 +153,40 @@ def test_both_forms_of_16_to_32_accumulators_on_short_launches(oracle, dbg_lib, 
     with bm.Chain("collapsed", 3000, 100, 20, seed=1, batch=400) as ch:
         shape = ch.kernel_shape()
     assert shape["threads"] == (1024 if not nosplit else shape["threads"])
+
+
+@pytest.mark.parametrize("noself", [False, True])
+def test_self_built_tables_equal_the_table_kernels(oracle, dbg_lib, noself):
+    """Small finite-sampler shapes: the resample workgroups build the table image themselves (no k_count_tables
+    between batches); BMM_DEBUG_NOSELF forces the ordinary path.  Both are the oracle's chain bit for bit -- over
+    many batches per sweep (the statistics are folded only at the end of a sweep in the first form), with sampled
+    and fixed alpha, with an emptied cluster, and when a sweep in between hands its probabilities to the host."""
+    if noself:
+        dbg_lib.setenv("BMM_DEBUG_NOSELF", "1")
+    else:
+        dbg_lib.delenv("BMM_DEBUG_NOSELF", raising=False)
+    for N, P, K, batch, alpha in [(100000, 20, 3, 12500, 0.0), (5000, 5, 2, 64, 0.0), (3000, 30, 4, 1, 1.5), (777, 120, 1, 100, 0.0),
+                                  (4000, 12, 9, 500, 0.3), (2500, 40, 3, 2500, 0.0)]:
+        X, _, _, _ = synth(N, P, min(K, 3), N + P)
+        z0 = _z0(N, K, 3)
+        if K == 4:
+            z0[z0 == 4] = 1                      # an empty cluster: stays empty (probability exactly 0)
+        sweeps = 3 if batch == 1 else 6
+        got = bm.gibbs_collapsed(X, sweeps, K, alpha=alpha if alpha else None, burnin=0, seed=5, batch=batch, initial_K=z0)
+        want = oracle.collapsed(X, z0, sweeps, K, alpha, 0.5, 0.5, 1, 1, 0, seed=5, batch=batch)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, N, P, K, batch)
+    X, _, _, _ = synth(6000, 20, 3, 4)
+    z0 = _z0(6000, 3, 2)
+    with bm.Chain("collapsed", 6000, 20, 3, batch=750, seed=9) as ch:
+        ch.set_data(X)
+        ch.set_initial_labels(z0)
+        ch.sweeps(2)
+        probs = ch.sweep_probs()                 # sweep 3 runs the emitting twin on k_count_tables' image
+        ch.sweeps(2)
+        z = ch.labels()
+        shape = ch.kernel_shape()
+    want = oracle.collapsed(X, z0, 6, 3, 0.0, 0.5, 0.5, 1, 1, 5, seed=9, batch=750)
+    assert np.array_equal(z, want["z"][0])
+    np.testing.assert_allclose(probs.sum(axis=1), 1.0, rtol=0, atol=1e-14)
+    assert shape["threads"] == 256
