@@ -1949,12 +1949,13 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int
             if (rc == BMM_OK) rc = run_start_state(c, io);
             if (rc) return rc;
             clock.lap(1);
-            if (host_pack && c->bits && (pack.join(), pack.failed.load() == 0)) {
+            pack.join();
+            if (host_pack && c->bits && pack.failed.load() == 0) {
                 if (pack.seen.load() & ~1u) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
                 rc = chain_set_planes_host(c, pack.words.get());
                 pack.words.reset();
-            } else {
-                pack.join();
+            } else {  // the int32 layout (test variant), or the workers could not be started: the resident API's way
+                pack.words.reset();
                 rc = bmm_chain_set_data_host(c, X);
             }
             if (rc) return rc;
