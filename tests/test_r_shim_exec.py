@@ -118,6 +118,56 @@ def R(tmp_path_factory):
     return MockR(so)
 
 
+@pytest.fixture(scope="module")
+def Rfwd(tmp_path_factory):
+    """the shim built with -DBMM_SHIM_FORWARD, beside test doubles of what it then links against
+    (tests/r_api_stub/fake_glue.c): its relabel = TRUE dispatch and the three forwarded entry points, executed"""
+    gcc = shutil.which("gcc")
+    if _build.stale(_build.LIB):
+        _build.build()
+    so = str(tmp_path_factory.mktemp("shimfwd") / "libshim_forward_under_mock_r.so")
+    libdir = os.path.dirname(_build.LIB)
+    subprocess.run([gcc, "-shared", "-fPIC", "-std=gnu11", "-O1", "-Wall", "-Wno-unused-parameter", "-Wno-cast-function-type",
+                    "-DBMM_SHIM_FORWARD", "-I" + STUB, "-I" + os.path.join(ROOT, "include"), os.path.join(STUB, "mock_r.c"),
+                    os.path.join(STUB, "fake_glue.c"), SHIM, "-L" + libdir, "-lbmmmcmc_hip", "-Wl,-rpath," + libdir, "-o", so],
+                   check=True, capture_output=True)
+    return MockR(so)
+
+
+def test_forward_build_hands_relabel_calls_to_the_glue(Rfwd):
+    """-DBMM_SHIM_FORWARD: relabel = TRUE on any of the eight sampler entry points reaches relabel_glue.cpp's
+    function for that sampler with the seed, batch and device the shim resolved (here: test doubles that report
+    what they were given); the three untouched entry points are the package's own functions."""
+    R = Rfwd
+    X, z0 = _x(), np.ones(400, dtype=np.int32)
+
+    def fields(r):
+        L = R.L
+        name_sexp = L.mock_elt(L.mock_elt(r, 0), 0)                  # STRSXP -> CHARSXP
+        name = C.string_at(L.mock_data(name_sexp)).decode()
+        vals = [R.value(L.mock_elt(r, i)) if L.mock_type(L.mock_elt(r, i)) in (INTSXP, REALSXP, LGLSXP) else None for i in (1, 2, 3)]
+        return name, [None if v is None else float(v[0]) for v in vals]
+
+    reads = R.L.mock_rng_reads()
+    name, (seed, batch, dev) = fields(R.call("_bmmmcmc_collapsed_gibbs_cpp", X, z0, 10, 2, 0.0, 0.5, 0.5, 1.0, 1.0, 5, True, 3, False))
+    assert name == "collapsed" and batch == 0 and dev == 0 and 0 <= seed < 2 ** 53 and seed == int(seed)
+    assert R.L.mock_rng_reads() == reads + 1                          # the seed came from R's stream
+    name, (seed, batch, dev) = fields(R.call("_bmmmcmc_collapsed_gibbs_dp_ex", X, 10, 0.0, 0.5, 0.5, 1.0, 1.0, 5, True, 3, 30, False,
+                                             7.0, 64.0, 1, np.array([2], dtype=np.int32)))
+    assert (name, seed, batch, dev) == ("dp", 7.0, 64.0, 2.0)
+    pi0, th0 = np.ones(4) / 4, np.full((4, 6), 0.5)
+    name, (seed, burnrelabel, dev) = fields(R.call("_bmmmcmc_gibbs_stickbreaking_cpp", X, pi0, th0, 10, 4, 0.0, 0.5, 0.5, 1.0, 1.0, 5,
+                                                   True, 3, False))
+    assert name == "sb" and burnrelabel == 3 and dev == 0
+    name, (seed, _, dev) = fields(R.call("_bmmmcmc_gibbs_ex", X, pi0, th0, 10, 4, 0.0, 0.5, 0.5, 1.0, 1.0, 5, True, 3, False, 11.0, 1, None))
+    assert (name, seed, dev) == ("full", 11.0, 0.0)
+    with pytest.raises(RuntimeError, match="one chain per call"):
+        R.call("_bmmmcmc_collapsed_gibbs_ex", X, np.ones((400, 2), dtype=np.int32), 10, 2, 0.0, 0.5, 0.5, 1.0, 1.0, 5, True, 3, False,
+               None, None, 2, None)
+    assert fields(R.call("_bmmmcmc_my_lpsolve", 1.0))[0] == "my_lpsolve"          # forwarded, not the error stub
+    assert fields(R.call("_bmmmcmc_my_stephens_batch", 1.0, False))[0] == "my_stephens_batch"
+
+
 def _x(N=400, P=6, seed=3):
     rng = np.random.default_rng(seed)
     return np.asfortranarray((rng.random((N, P)) < 0.4).astype(np.int32))
