@@ -46,6 +46,17 @@ const char* dbg_env(const char* name) { return getenv(name); }
 const char* dbg_env(const char*) { return nullptr; }
 #endif
 
+// Test variant only (BMM_DEBUG_FAKE_DEVICES=n): the library then accepts device indices 0 .. n-1, all of them the one
+// real device underneath, keeps them apart wherever it reasons about which chains share a device (bmm_multi_run's
+// placement, bmm_chain_share_data, bmm_chains_broadcast_planes), and replaces the RCCL broadcast between them by
+// device-to-device copies.  What a one-GPU box can run of the multi-device bookkeeping -- every line of it but the
+// collective itself, which bmm_multi_selfcheck runs on the device there is.  The product library has no such mode.
+int fake_devices() {
+    const char* v = dbg_env("BMM_DEBUG_FAKE_DEVICES");
+    const int n = v ? atoi(v) : 0;
+    return n > 1 ? n : 0;
+}
+
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -492,7 +503,8 @@ resample_fn resample_kernel_small_of(int kt, int minus, bool bits) {
 
 struct bmm_chain {
     ChainParams p{};
-    int device = 0;
+    int device = 0;  // the HIP device
+    int slot = 0;    // the device index the caller named (= device, except under BMM_DEBUG_FAKE_DEVICES)
     hipStream_t stream = nullptr;
     bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
     bool plain_stream = false;     // ... or is an ordinary non-blocking stream, which the pool takes back
@@ -1129,6 +1141,11 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_err(BMM_E_NODEVICE, "no HIP device visible; this path has no CPU fallback");
+    const int slot = device;
+    if (const int fake = fake_devices()) {
+        if (device < 0 || device >= fake) return set_err(BMM_E_ARG, "device %d out of range (have %d)", device, fake);
+        device = device % ndev;
+    }
     if (device < 0 || device >= ndev) return set_err(BMM_E_ARG, "device %d out of range (have %d)", device, ndev);
 
     bmm_chain* c = new (std::nothrow) bmm_chain();
@@ -1144,6 +1161,7 @@ int bmm_chain_create(bmm_chain** out, int sampler, int64_t N, int P, int K, doub
     p.sample_alpha = alpha == 0.0;  // collapsed_gibbs.cpp:50-54
     c->alpha0 = p.sample_alpha ? 1.0 : alpha;
     c->device = device;
+    c->slot = slot;
     c->batch = batch <= 0 ? default_batch(sampler, N) : (batch > N ? N : batch);
     if (explicit_params(sampler)) c->batch = N;
     if (p.Kc > kMaxCatsAny) {
@@ -1345,7 +1363,7 @@ int bmm_chain_share_data(bmm_chain* c, bmm_chain* from) {
     if (!c || !from) return set_err(BMM_E_ARG, "null argument");
     if (c->started || c->have_data) return set_err(BMM_E_STATE, "the chain already has its data");
     if (!from->have_data || !from->bits || !from->dXb) return set_err(BMM_E_STATE, "the source chain holds no bit planes");
-    if (from->device != c->device) return set_err(BMM_E_ARG, "chains on different devices cannot share planes");
+    if (from->slot != c->slot) return set_err(BMM_E_ARG, "chains on different devices cannot share planes");
     if (from->p.N != c->p.N || from->p.P != c->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
     if (!c->bits) return set_err(BMM_E_STATE, "the int32 layout streams the caller's matrix: hand it over instead");
     int rcq = chain_dedicated_queue(from);  // two chains on one device: a hardware queue each
@@ -2001,6 +2019,11 @@ int rccl_open(Rccl& r) {
 int rccl_broadcast_words(const std::vector<int>& devs, const std::vector<void*>& bufs, size_t count) {
     const int n = (int)devs.size();
     if (n < 2) return BMM_OK;
+    if (fake_devices()) {  // test variant: the "devices" are one device; the broadcast is a copy per receiver
+        for (int q = 1; q < n; ++q) HIP_TRY(hipMemcpy(bufs[(size_t)q], bufs[0], count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipDeviceSynchronize());
+        return BMM_OK;
+    }
     Rccl r;
     int rc = rccl_open(r);
     if (rc) return rc;
@@ -2244,9 +2267,9 @@ int bmm_chains_broadcast_planes(bmm_chain* const* chains, int n_chains) {
             bmm_chain* ch = chains[c];
             if (!ch) return set_err(BMM_E_ARG, "null chain");
             for (int d : devs)
-                if (d == ch->device) return set_err(BMM_E_ARG, "one chain per device here; chains on one device share (bmm_chain_share_data)");
+                if (d == ch->slot) return set_err(BMM_E_ARG, "one chain per device here; chains on one device share (bmm_chain_share_data)");
             if (ch->p.N != chains[0]->p.N || ch->p.P != chains[0]->p.P) return set_err(BMM_E_ARG, "the chains differ in N or P");
-            devs.push_back(ch->device);
+            devs.push_back(ch->slot);
             int rc = bmm_chain_planes(ch, &bufs[(size_t)c], &words);
             if (rc) return rc;
         }

@@ -189,3 +189,44 @@ def test_bench_line_of_a_two_rank_job_rehearsed_on_one_gpu():
     assert "REHEARSAL" in m["launcher"] and m["plane_bytes"] == 4 * 100_000
     assert d["config"]["chains"] == 2 and d["value"] > 0
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]    # value = chains x steps / max time
+
+
+def test_multi_device_bookkeeping_on_fake_devices(oracle, dbg_lib):
+    """The test variant's BMM_DEBUG_FAKE_DEVICES=2: device indices 0 and 1 are both the one GPU, kept apart wherever
+    the library reasons about devices, the RCCL broadcast between them replaced by a copy.  bmm_multi_run with
+    devices = {0, 1, 0, 1} then runs everything it would run on two GPUs except the collective itself: placement,
+    a holder of the planes per device, receivers declaring theirs filled, chains 2 and 3 sharing with the holder of
+    THEIR device, one host thread per chain -- and every chain is its oracle chain (seed + c)."""
+    dbg_lib.setenv("BMM_DEBUG_FAKE_DEVICES", "2")
+    X, _, _, _ = synth(5000, 24, 3, 6)
+    z0s = [_z0(5000, 3, 10 + c) for c in range(4)]
+    outs = bm.gibbs_collapsed(X, 8, 3, burnin=2, seed=40, batch=700, chains=4, devices=[0, 1, 0, 1], initial_K=z0s)
+    for c, out in enumerate(outs):
+        want = oracle.collapsed(X, z0s[c], 8, 3, 0.0, 0.5, 0.5, 1, 1, 2, seed=40 + c, batch=700)
+        assert np.array_equal(out["z"], want["z"]) and np.array_equal(out["theta"], want["theta"], equal_nan=True), c
+    outs = bm.gibbs_dp(X, 7, burnin=1, maxK=9, seed=3, batch=300, chains=3, devices=[1, 0, 1])   # device 1 named first: it packs
+    for c, out in enumerate(outs):
+        want = oracle.dp(X, 7, 0.0, 0.5, 0.5, 1, 1, 1, 9, seed=3 + c, batch=300)
+        assert np.array_equal(out["z"], want["z"]), c
+    with pytest.raises(bm.BmmError, match="out of range"):
+        bm.gibbs_collapsed(X, 4, 3, seed=1, chains=2, devices=[0, 2])
+    # resident chains, one per "device": the second receives the first one's planes (bmm_chains_broadcast_planes)
+    a, b = bm.Chain("collapsed", 5000, 24, 3, seed=7, batch=512, device=0), bm.Chain("collapsed", 5000, 24, 3, seed=8, batch=512, device=1)
+    third = bm.Chain("collapsed", 5000, 24, 3, seed=9, batch=512, device=1)
+    try:
+        a.set_data(X)
+        bm.broadcast_planes([a, b])
+        with pytest.raises(bm.BmmError, match="different devices"):
+            third.share_data(a)                      # a lives on device 0, third on device 1
+        third.share_data(b)
+        for ch, s in ((a, 7), (b, 8), (third, 9)):
+            ch.set_initial_labels(z0s[0])
+        bm.sweep_chains([a, b, third], 4)
+        for ch, s in ((a, 7), (b, 8), (third, 9)):
+            want = oracle.collapsed(X, z0s[0], 5, 3, 0.0, 0.5, 0.5, 1, 1, 4, seed=s, batch=512)
+            assert np.array_equal(ch.labels(), want["z"][0]), s
+        with pytest.raises(bm.BmmError, match="one chain per device"):
+            bm.broadcast_planes([a, b, third])
+    finally:
+        for ch in (third, b, a):
+            ch.close()
