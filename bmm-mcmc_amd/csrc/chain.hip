@@ -229,11 +229,12 @@ struct StagePool {
         if (hipHostMalloc(&p, kStageBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         return p;
     }
-    void put(void* p) {
+    void put(void* p) noexcept {  // called from destructors: a piece that cannot be kept is freed
         if (!p) return;
-        {
+        try {
             std::lock_guard<std::mutex> g(m);
             if (idle.size() < 8) { idle.push_back(p); return; }
+        } catch (...) {
         }
         (void)hipHostFree(p);
     }
@@ -269,14 +270,17 @@ struct DevPool {
         *got = bytes;
         return p;
     }
-    void put(int device, void* p, size_t bytes) {
+    void put(int device, void* p, size_t bytes) noexcept {
         if (!p) return;
-        if (device >= 0 && device < 64) {
-            std::lock_guard<std::mutex> g(m);
-            std::vector<Block>& v = idle[device];
-            size_t held = 0;
-            for (const Block& b : v) held += b.bytes;
-            if (v.size() < 6 && held + bytes <= kMaxIdleBytes) { v.push_back(Block{p, bytes}); return; }
+        try {
+            if (device >= 0 && device < 64) {
+                std::lock_guard<std::mutex> g(m);
+                std::vector<Block>& v = idle[device];
+                size_t held = 0;
+                for (const Block& b : v) held += b.bytes;
+                if (v.size() < 6 && held + bytes <= kMaxIdleBytes) { v.push_back(Block{p, bytes}); return; }
+            }
+        } catch (...) {
         }
         (void)hipFree(p);
     }
@@ -677,12 +681,16 @@ struct StreamPool {
         idle[device].pop_back();
         return s;
     }
-    bool put(int device, hipStream_t s) {
+    bool put(int device, hipStream_t s) noexcept {
         if (device < 0 || device >= 64) return false;
-        std::lock_guard<std::mutex> g(m);
-        if (idle[device].size() >= 4) return false;
-        idle[device].push_back(s);
-        return true;
+        try {
+            std::lock_guard<std::mutex> g(m);
+            if (idle[device].size() >= 4) return false;
+            idle[device].push_back(s);
+            return true;
+        } catch (...) {
+            return false;
+        }
     }
 };
 StreamPool& stream_pool() { static StreamPool* const pool = new StreamPool(); return *pool; }  // never destroyed: no HIP call at exit
@@ -2218,9 +2226,16 @@ int bmm_multi_run(int sampler, int n_chains, const int* devices, const int32_t* 
             tg.th.reserve((size_t)n_chains);
             for (int c = 0; c < n_chains; ++c)
                 tg.th.emplace_back([&, c]() {
-                    status[(size_t)c] = run_start_state(chains[(size_t)c], io[(size_t)c]);
-                    if (status[(size_t)c] == BMM_OK) status[(size_t)c] = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
-                    if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                    // no exception may leave a thread: the trace's way out starts helper threads of its own
+                    status[(size_t)c] = guarded([&]() -> int {
+                        int rcw = run_start_state(chains[(size_t)c], io[(size_t)c]);
+                        if (rcw == BMM_OK) rcw = run_body(chains[(size_t)c], nsamples, io[(size_t)c], nullptr);
+                        return rcw;
+                    });
+                    try {
+                        if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                    } catch (...) {  // the message could not be copied: the status stands
+                    }
                 });
         }
         for (int c = 0; c < n_chains; ++c)
@@ -2242,8 +2257,11 @@ int bmm_chains_sweeps(bmm_chain* const* chains, int n_chains, int sweeps) {
             tg.th.reserve((size_t)n_chains);
             for (int c = 0; c < n_chains; ++c)
                 tg.th.emplace_back([&, c]() {
-                    status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);
-                    if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                    status[(size_t)c] = bmm_chain_sweeps(chains[c], sweeps);  // guarded inside
+                    try {
+                        if (status[(size_t)c]) msg[(size_t)c] = bmm_last_error();
+                    } catch (...) {
+                    }
                 });
         }
         for (int c = 0; c < n_chains; ++c)
