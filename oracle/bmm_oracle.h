@@ -11,7 +11,10 @@
  *     recomputed from the cited reference lines with NumPy (tests/golden/make_kats.py);
  *   - the bundled datasets' documented generating parameters (R/bmm-mcmc.R:13-17,
  *     31-35, 46-50) as statistical acceptance bounds;
- *   - Philox4x32-10 and Philox2x32-10 against the Random123 known-answer vectors.
+ *   - Philox4x32-10 and Philox2x32-10 against the Random123 known-answer vectors;
+ *   - the stationary law of the batch-1 chains against the exact posterior by enumeration of every
+ *     allocation of seven observations (scipy log-beta / log-gamma; tests/test_oracle_posterior.py): DP,
+ *     stick-breaking, full sampler, and the alpha update against quadrature.
  *
  * Two restatements per sampler:
  *   *_literal : the reference algorithm as written -- per-cluster member lists,
