@@ -92,9 +92,9 @@ def test_c3_dp_and_c4_stickbreaking_full_size_invariants(name):
 
 @pytest.mark.timeout(600)
 def test_host_matrix_uploaded_in_slabs_equals_the_device_matrix_packed_at_once():
-    """bmm_chain_set_data_host passes the int32 matrix through a 256 MiB staging buffer in slabs of
-    rows (here two, the second with a row count that is not a multiple of four); the bit planes must
-    be the ones a matrix already on the device gives."""
+    """bmm_chain_set_data_host has the host's cores validate and pack the int32 matrix slab by slab into pinned
+    staging (here three slabs of 4 MiB of packed words, the last one ragged) and uploads only the bit planes;
+    they must be the ones k_pack_bits makes from a matrix already on the device."""
     import torch
     import bmm_mcmc_amd as bm
     N, P, K = 2_500_003, 30, 6
