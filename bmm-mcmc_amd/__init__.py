@@ -18,7 +18,7 @@ from . import _capi
 from ._capi import BmmError, NA_INTEGER
 from .rdata import read_rdata_matrix  # the package's bundled data sets (data/*.RData) without R
 
-__all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER",
+__all__ = ["gibbs_collapsed", "gibbs_dp", "gibbs_stickbreaking", "gibbs_full", "Chain", "BmmError", "NA_INTEGER", "set_progress",
            "default_batch", "sweep_chains", "broadcast_planes", "read_rdata_matrix", "chain_summary", "TOL_PROPORTIONS", "TOL_THETA"]
 
 # include/bmm_mcmc.h: the stated tolerance of a batch > 1 against the reference's sequential scan
@@ -120,6 +120,44 @@ class _Relabel:
         return out
 
 
+# ---------------------------------------------------------------- progress ("Sample j", as the reference prints it)
+_PROGRESS_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_int, _C.c_int)
+_progress_every = 0
+
+
+def set_progress(every=0):
+    """The reference prints "Sample j" at every sweep (src/collapsed_gibbs.cpp:85; gibbs_dp adds the number of
+    clusters, src/collapsed_gibbs_dp.cpp:99).  Here a run is silent unless asked: set_progress(100) prints that
+    line every 100 sweeps of the single-chain calls that follow, set_progress(0) turns it off; debug=True prints
+    every sweep.  Returns the previous setting (the R wrapper is bmm_progress(), R/gibbs.R)."""
+    global _progress_every
+    old, _progress_every = _progress_every, max(0, int(every))
+    return old
+
+
+def _print_progress(user, sample, nsamples, k_used):
+    print("Sample %d" % sample if k_used < 0 else "Sample %d\tK: %d" % (sample, k_used), flush=True)
+    return 0
+
+
+_progress_cb = _PROGRESS_FN(_print_progress)
+
+
+class _progress:
+    """the hook around one run: every sweep with debug=True, else what set_progress asked for"""
+
+    def __init__(self, debug):
+        self.every = 1 if debug else _progress_every
+
+    def __enter__(self):
+        if self.every:
+            _capi.lib().bmm_set_progress(_progress_cb, None, _C.c_int(self.every))
+
+    def __exit__(self, *exc):
+        if self.every:
+            _capi.lib().bmm_set_progress(_PROGRESS_FN(0), None, _C.c_int(0))
+
+
 def _clamp_burnrelabel(burnrelabel, burnin):
     return int(round(0.1 * burnin)) if burnrelabel > burnin else int(burnrelabel)  # R/utils.R:26,41,72
 
@@ -198,12 +236,13 @@ def gibbs_collapsed(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1
     z = _np.empty((S, N), dtype=_np.int32, order="F")  # every cell is written by the library
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
-    rc = _capi.lib().bmm_collapsed_run_probs(
-        _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(z0), _C.c_int(nsamples), _C.c_int(K),
-        _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
-        _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int64(0 if batch is None else batch),
-        _C.c_uint64(seed), _C.c_int(device), _capi.vp(z), _capi.vp(theta), _capi.vp(al),
-        rl.ref() if rl else None)
+    with _progress(debug):
+        rc = _capi.lib().bmm_collapsed_run_probs(
+            _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(z0), _C.c_int(nsamples), _C.c_int(K),
+            _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
+            _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int64(0 if batch is None else batch),
+            _C.c_uint64(seed), _C.c_int(device), _capi.vp(z), _capi.vp(theta), _capi.vp(al),
+            rl.ref() if rl else None)
     out = {"alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
     if rl:
         return rl.finish(rc, out)
@@ -231,12 +270,13 @@ def gibbs_dp(data, nsamples, alpha=None, a=1, b=1, beta=0.5, gamma=0.5, burnin=N
     z = _np.empty((S, N), dtype=_np.int32, order="F")  # every cell is written by the library
     theta = _np.zeros((maxK, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
-    rc = _capi.lib().bmm_dp_run_probs(
-        _capi.vp(X), _C.c_int64(N), _C.c_int(P), _C.c_int(nsamples),
-        _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
-        _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int(maxK),
-        _C.c_int64(0 if batch is None else batch), _C.c_uint64(seed), _C.c_int(device), _capi.vp(z),
-        _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
+    with _progress(debug):
+        rc = _capi.lib().bmm_dp_run_probs(
+            _capi.vp(X), _C.c_int64(N), _C.c_int(P), _C.c_int(nsamples),
+            _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta), _C.c_double(gamma),
+            _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_int(maxK),
+            _C.c_int64(0 if batch is None else batch), _C.c_uint64(seed), _C.c_int(device), _capi.vp(z),
+            _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
     out = {"alpha": al, "permutations": _na_perm(S, maxK), "z": z, "theta": theta}
     if rl:
         return rl.finish(rc, out)
@@ -245,7 +285,7 @@ def gibbs_dp(data, nsamples, alpha=None, a=1, b=1, beta=0.5, gamma=0.5, burnin=N
 
 
 def _explicit(sampler, fn, clamp, data, nsamples, K, alpha, beta, gamma, a, b, burnin, relabel, burnrelabel, seed,
-              device, initial_pi, initial_theta, chains, devices, stephens):
+              device, initial_pi, initial_theta, chains, devices, stephens, debug=False):
     X = _capi.as_x(data)
     N, P = X.shape
     nsamples, K = int(nsamples), int(K)
@@ -281,11 +321,12 @@ def _explicit(sampler, fn, clamp, data, nsamples, K, alpha, beta, gamma, a, b, b
     theta = _np.zeros((K, P, S), order="F")
     al = _np.zeros((S, 1), order="F")
     pi = _np.zeros((S, K), order="F")
-    rc = getattr(_capi.lib(), fn)(
-        _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(pi0), _capi.vp(th0), _C.c_int(nsamples),
-        _C.c_int(K), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta),
-        _C.c_double(gamma), _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed),
-        _C.c_int(device), _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
+    with _progress(debug):
+        rc = getattr(_capi.lib(), fn)(
+            _capi.vp(X), _C.c_int64(N), _C.c_int(P), _capi.vp(pi0), _capi.vp(th0), _C.c_int(nsamples),
+            _C.c_int(K), _C.c_double(0.0 if alpha is None else alpha), _C.c_double(beta),
+            _C.c_double(gamma), _C.c_double(a), _C.c_double(b), _C.c_int(burnin), _C.c_uint64(seed),
+            _C.c_int(device), _capi.vp(pi), _capi.vp(z), _capi.vp(theta), _capi.vp(al), rl.ref() if rl else None)
     out = {"pi": pi, "alpha": al, "permutations": _na_perm(S, K), "z": z, "theta": theta}
     if rl:
         return rl.finish(rc, out)
@@ -299,7 +340,7 @@ def gibbs_stickbreaking(data, nsamples, maxK, alpha=None, beta=0.5, gamma=0.5, a
     """Blocked Gibbs sampler, truncated stick-breaking prior (R/utils.R:95-107 ->
     src/stickbreaking.cpp:10).  The z-step is exactly parallel, so there is no batch."""
     return _explicit("stickbreaking", "bmm_sb_run_probs", False, data, nsamples, maxK, alpha, beta, gamma, a, b,
-                     burnin, relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens)
+                     burnin, relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens, debug)
 
 
 def gibbs_full(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, burnin=None, relabel=False,
@@ -307,7 +348,7 @@ def gibbs_full(data, nsamples, K, alpha=None, beta=0.5, gamma=0.5, a=1, b=1, bur
                devices=None, stephens=None):
     """Full (uncollapsed) Gibbs sampler, finite K (R/utils.R:64-78 -> src/full_gibbs.cpp:32)."""
     return _explicit("full", "bmm_full_run_probs", True, data, nsamples, K, alpha, beta, gamma, a, b, burnin,
-                     relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens)
+                     relabel, burnrelabel, seed, device, initial_pi, initial_theta, chains, devices, stephens, debug)
 
 
 class Chain:

@@ -58,6 +58,24 @@ def test_progress_hook_reports_every_mth_sweep_and_the_chain_is_unchanged(oracle
         assert k_used == len(np.unique(got["z"][sample - 1]))
 
 
+def test_python_mirror_prints_the_sample_line(capfd):
+    """debug=True prints "Sample j" every sweep as the reference does (collapsed_gibbs.cpp:85; with K for gibbs_dp,
+    collapsed_gibbs_dp.cpp:99); bm.set_progress(M) every M sweeps; silent otherwise"""
+    X, _, _, _ = synth(1500, 8, 2, 4)
+    bm.gibbs_collapsed(X, 5, 2, burnin=1, seed=5)
+    assert "Sample" not in capfd.readouterr().out
+    bm.gibbs_collapsed(X, 5, 2, burnin=1, seed=5, debug=True)
+    assert capfd.readouterr().out == "".join("Sample %d\n" % j for j in range(2, 6))
+    assert bm.set_progress(2) == 0
+    out = bm.gibbs_dp(X, 6, burnin=0, maxK=7, seed=5)
+    lines = capfd.readouterr().out.splitlines()
+    assert [l.split("\t")[0] for l in lines] == ["Sample 3", "Sample 5", "Sample 6"]
+    assert lines[0] == "Sample 3\tK: %d" % len(np.unique(out["z"][2]))
+    bm.gibbs_stickbreaking(X, 4, 3, burnin=1, seed=5, debug=True)
+    assert capfd.readouterr().out == "Sample 2\nSample 3\nSample 4\n"
+    assert bm.set_progress(0) == 2
+
+
 def test_progress_hook_can_stop_the_run():
     X, _, _, _ = synth(2000, 10, 2, 4)
     with _Progress(2, stop_at=5) as p:
