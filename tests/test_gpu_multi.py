@@ -230,3 +230,36 @@ def test_multi_device_bookkeeping_on_fake_devices(oracle, dbg_lib):
     finally:
         for ch in (third, b, a):
             ch.close()
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_contract_on_one_gpu():
+    """the ONE JSON line `python bench.py` prints: the keys the driver reads, the roofline and cpu_baseline objects"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "8", "--warmup", "2", "--burn", "4",
+                        "--no-extra", "--cpu-seconds", "1", "--cpu-rows", "20000"], capture_output=True, text=True, timeout=500,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["higher_is_better"], d["scaling"], d["vs_baseline"]) == (1, 8, 2, True, "weak", None)
+    assert d["unit"] == "sweeps/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["kernel_ms_per_sweep"] <= d["ms_per_step"]               # the kernel's time is part of the sweep's
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
