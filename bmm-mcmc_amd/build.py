@@ -16,7 +16,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "chain.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hip.h"), os.path.join(HERE, "csrc", "bmm_spec.h"),
-        os.path.join(HERE, "csrc", "bmm_exp256.h"), os.path.join(os.path.dirname(HERE), "include", "bmm_mcmc.h")]
+        os.path.join(HERE, "csrc", "bmm_exp256.h"), os.path.join(HERE, "csrc", "host_crew.h"),
+        os.path.join(os.path.dirname(HERE), "include", "bmm_mcmc.h")]
 LIB = os.path.join(HERE, "lib", "libbmmmcmc_hip.so")
 LIB_DBG = os.path.join(HERE, "lib", "libbmmmcmc_hip_dbg.so")
 

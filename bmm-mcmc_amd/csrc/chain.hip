@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen when a run spans devices
 
 #include <dlfcn.h>
+#include <emmintrin.h>
 #include <sched.h>
 
 #include <cmath>
@@ -20,18 +21,24 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/bmm_mcmc.h"
 #include "kernels.hip.h"
+#include "host_crew.h"
 
 using namespace bmm;
+using bmm_host::HostCrew;
+using bmm_host::host_threads;
 
 namespace {
 
@@ -102,61 +109,13 @@ struct ThreadGroup {
     void join() { for (std::thread& t : th) if (t.joinable()) t.join(); }
 };
 
-// CPUs this process may use for the host-side ends of a run (packing X on its way in, widening the label
-// trace on its way out): the affinity mask, cut to a cgroup CPU quota where there is one (a container that
-// is granted 16 of a host's 256 hardware threads), at most 16 -- memory bandwidth is what those loops need.
-int host_threads() {
-    static const int n = [] {
-        int n = 1;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
-        long long quota = -1, period = 0;
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
-            char q[32] = "";
-            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-            fclose(f);
-        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // v1
-            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-            fclose(g);
-            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (fscanf(h, "%lld", &period) != 1) period = 0;
-                fclose(h);
-            }
-        }
-        if (quota > 0 && period > 0) {
-            const int c = (int)((quota + period - 1) / period);
-            if (c >= 1 && c < n) n = c;
-        }
-        return n < 1 ? 1 : (n > 16 ? 16 : n);
-    }();
-    return n;
-}
-
-// f(lo, hi) over [0, n) in one contiguous range per thread (whole multiples of `align`), the calling thread
-// taking the first; f must not throw
-template <class F>
-void parallel_ranges(int64_t n, int64_t min_per_thread, int64_t align, F&& f) {
-    int64_t t = host_threads();
-    if (min_per_thread > 0 && n / min_per_thread < t) t = n / min_per_thread;
-    if (t <= 1) { f((int64_t)0, n); return; }
-    int64_t per = (n + t - 1) / t;
-    per = (per + align - 1) / align * align;
-    ThreadGroup tg;
-    tg.th.reserve((size_t)t);
-    for (int64_t lo = per; lo < n; lo += per) {
-        const int64_t hi = lo + per < n ? lo + per : n;
-        tg.th.emplace_back([&f, lo, hi]() { f(lo, hi); });
-    }
-    f((int64_t)0, per < n ? per : n);
-}
-
 // Observations [a, b) of the N x P int32 column-major matrix R hands over, as bit planes: word w of
-// observation i at out[w * ld + (i - a0)] (feature d at bit d % 32 of word d / 32, bits past P zero -- what
+// observation i at plane[w][i - a0] (feature d at bit d % 32 of word d / 32, bits past P zero -- what
 // k_pack_bits writes on the device).  Eight columns at a time into a block of output words that stays in L1:
 // every cell of X is read once, in long contiguous runs, eight independent streams in flight per thread (one
 // stream alone leaves a core at 6.5 GB/s, eight at 10).  Returns the OR of all cells read: the caller rejects
 // the matrix when that has a bit other than bit 0 (data must be 0/1, as k_validate_binary checks).
-uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b, uint32_t* out, int64_t ld, int64_t a0) {
+uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b, uint32_t* const* plane, int64_t a0) {
     constexpr int64_t BL = 4096;
     constexpr int NS = 8;
     const int W = (P + 31) / 32;
@@ -164,7 +123,7 @@ uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b
     for (int64_t r = a; r < b; r += BL) {
         const int64_t n = b - r < BL ? b - r : BL;
         for (int w = 0; w < W; ++w) {
-            uint32_t* __restrict const o = out + (int64_t)w * ld + (r - a0);
+            uint32_t* __restrict const o = plane[w] + (r - a0);
             const int d0 = 32 * w, nd = P - d0 < 32 ? P - d0 : 32;
             const uint32_t* const col = reinterpret_cast<const uint32_t*>(X) + (int64_t)d0 * N + r;
             int j = 0;
@@ -186,32 +145,6 @@ uint32_t pack_rows_host(const int32_t* X, int64_t N, int P, int64_t a, int64_t b
     }
     return seen;
 }
-
-// All of a host matrix packed by the worker threads while the calling thread goes on (a *_run call creates
-// its chain and uploads the starting state meanwhile); the planes land in ordinary host memory: [w][N].
-struct AsyncPack {
-    std::unique_ptr<uint32_t[]> words;
-    std::atomic<uint32_t> seen{0};
-    std::atomic<int> failed{0};  // the workers could not be started (no exception may leave a thread)
-    std::thread th;
-    void start(const int32_t* X, int64_t N, int P) {
-        const int W = (P + 31) / 32;
-        words.reset(new uint32_t[(size_t)W * (size_t)N]);
-        uint32_t* const out = words.get();
-        th = std::thread([this, X, N, P, out]() {
-            try {
-                parallel_ranges(N, 32768, 64, [&](int64_t lo, int64_t hi) {
-                    seen.fetch_or(pack_rows_host(X, N, P, lo, hi, out, N, 0), std::memory_order_relaxed);
-                });
-            } catch (...) {
-                failed.store(1);
-            }
-        });
-    }
-    bool running() const { return th.joinable(); }
-    void join() { if (th.joinable()) th.join(); }
-    ~AsyncPack() { join(); }
-};
 
 // Pinned staging in pieces of 4 MiB that outlive a call: pinning costs about a millisecond per piece, a run
 // needs two on the way in and two on the way out, and an R session calls the samplers again and again.  At
@@ -240,6 +173,50 @@ struct StagePool {
     }
 };
 StagePool& stage_pool() { static StagePool* const pool = new StagePool(); return *pool; }
+struct Stage {  // one piece, back to the pool on every return path
+    void* p = stage_pool().get();
+    ~Stage() { stage_pool().put(p); }
+    Stage() = default;
+    Stage(const Stage&) = delete;
+    Stage& operator=(const Stage&) = delete;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// All of a host matrix packed by the crew while the calling thread goes on (a *_run call creates its chain
+// and uploads the starting state meanwhile).  The planes land in pinned pieces of the staging pool, one per
+// plane, when a plane fits a piece and there are at most four (N <= 2^20, P <= 128: the upload then runs at
+// PCIe speed, 0.15 instead of 0.6 ms for the 8 MB of the north-star shape); in ordinary host memory, [w][N],
+// otherwise.
+struct AsyncPack {
+    std::unique_ptr<uint32_t[]> words;
+    std::unique_ptr<Stage[]> pinned;
+    std::vector<uint32_t*> plane;
+    std::atomic<uint32_t> seen{0};
+    HostCrew* crew = nullptr;
+    void start(HostCrew* cr, const int32_t* X, int64_t N, int P) {
+        const int W = (P + 31) / 32;
+        crew = cr;
+        plane.assign((size_t)W, nullptr);
+        if (W <= 4 && (size_t)N * sizeof(uint32_t) <= kStageBytes) {
+            pinned.reset(new Stage[(size_t)W]);
+            bool ok = true;
+            for (int w = 0; w < W; ++w) { plane[(size_t)w] = pinned[(size_t)w].as<uint32_t>(); ok = ok && plane[(size_t)w]; }
+            if (!ok) pinned.reset();
+        }
+        if (!pinned) {
+            words.reset(new uint32_t[(size_t)W * (size_t)N]);
+            for (int w = 0; w < W; ++w) plane[(size_t)w] = words.get() + (size_t)w * (size_t)N;
+        }
+        uint32_t* const* const pl = plane.data();
+        std::atomic<uint32_t>* const sn = &seen;
+        crew->begin(N, 32768, 64, [X, N, P, pl, sn](int64_t lo, int64_t hi) {
+            sn->fetch_or(pack_rows_host(X, N, P, lo, hi, pl, 0), std::memory_order_relaxed);
+        });
+    }
+    void join() { if (crew) crew->wait(); }
+    void release() { join(); words.reset(); pinned.reset(); plane.clear(); }
+    ~AsyncPack() { join(); }
+};
 
 // Device memory of a finished call, kept for the next one: a chain's arena, a run's arena and the bit planes
 // come from here.  hipMalloc is usually free on this runtime (0.02 ms) but now and then takes 10 ms and more
@@ -276,9 +253,17 @@ struct DevPool {
             if (device >= 0 && device < 64) {
                 std::lock_guard<std::mutex> g(m);
                 std::vector<Block>& v = idle[device];
-                size_t held = 0;
-                for (const Block& b : v) held += b.bytes;
-                if (v.size() < 6 && held + bytes <= kMaxIdleBytes) { v.push_back(Block{p, bytes}); return; }
+                if (bytes <= kMaxIdleBytes) {  // the newest block stays, the oldest go: a session repeats its last shape
+                    size_t held = bytes;
+                    for (const Block& b : v) held += b.bytes;
+                    while (!v.empty() && (v.size() >= 6 || held > kMaxIdleBytes)) {
+                        held -= v.front().bytes;
+                        (void)hipFree(v.front().p);
+                        v.erase(v.begin());
+                    }
+                    v.push_back(Block{p, bytes});
+                    return;
+                }
             }
         } catch (...) {
         }
@@ -286,11 +271,6 @@ struct DevPool {
     }
 };
 DevPool& dev_pool() { static DevPool* const pool = new DevPool(); return *pool; }
-struct Stage {  // one piece, back to the pool on every return path
-    void* p = stage_pool().get();
-    ~Stage() { stage_pool().put(p); }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
 
 // pinned host staging that is released on every return path
 struct PinnedBuf {
@@ -508,10 +488,11 @@ resample_fn resample_kernel_small_of(int kt, int minus, bool bits) {
 struct bmm_chain {
     ChainParams p{};
     int device = 0;  // the HIP device
+    HostCrew* crew = nullptr;  // the host threads of the *_run call this chain belongs to (not owned), if any
     int slot = 0;    // the device index the caller named (= device, except under BMM_DEBUG_FAKE_DEVICES)
     hipStream_t stream = nullptr;
     bool dedicated_queue = false;  // the stream has a hardware queue of its own (chains sharing a device)
-    bool plain_stream = false;     // ... or is an ordinary non-blocking stream, which the pool takes back
+    int stream_kind = 0;           // what the stream pool takes back: 1 an ordinary non-blocking stream, 2 one with its own queue, 0 neither
     bool shares_device = false;    // another chain runs beside this one on the device (bmm_chain_share_data)
     bool self_tables = false;      // the resample workgroups build their own table image: no k_count_tables per batch
     size_t lds_bytes_base = 0;     // lds_bytes without the SELF kernels' scratch
@@ -563,6 +544,8 @@ struct bmm_chain {
     int32_t* dNkTrace = nullptr;  // [n][K] cluster sizes per sweep of the current sweeps_counts call
     int nk_trace_base = 0;        // sweep index of its row 0
     unsigned long long* dDiag = nullptr;
+    int* dSelfDone = nullptr;     // SELF kernels: workgroups of the running launch that have read the statistics
+    int32_t *dDNkAlt = nullptr, *dDSAlt = nullptr;  // ... and the second set of delta accumulators (self_fold_prev)
     int* dDbgFlag = nullptr;      // -DBMM_DEBUG_HOOKS: raised by a kernel that meets a label out of range
     int prof = 0;             // > 0: HIP events around the resample launches of every prof-th sweep
     std::vector<hipEvent_t> ev;
@@ -673,27 +656,32 @@ int device_cus(int device) {
     return cus[device];
 }
 
-// Plain streams outlive their chain: creating and destroying one costs about 2 ms each on this runtime
+// Streams outlive their chain: creating and destroying a plain one costs about 2 ms each on this runtime
 // (tools/hipcost_probe.hip), a fifth of what the rest of a 220-sweep drop-in call at the north-star shape
-// spends outside its sweeps.  A destroyed chain's (idle) plain stream goes back here, up to four per device;
-// streams with a hardware queue of their own (chains sharing a device) are created and destroyed as before.
+// spends outside its sweeps; one with a hardware queue of its own (chains sharing a device) costs 6 ms, and a
+// process that created and destroyed four of those per call was seen to hang inside the runtime's queue
+// creation after some hundred calls (a runtime thread stuck in the driver's queue ioctl, the caller waiting for
+// its lock: profiles/r03/README.md).  A destroyed chain's (idle) stream goes back here, up to four of either
+// kind per device.
 struct StreamPool {
     std::mutex m;
-    std::vector<hipStream_t> idle[64];
-    hipStream_t get(int device) {
+    std::vector<hipStream_t> idle[2][64];  // [0] plain, [1] with a hardware queue of their own
+    hipStream_t get(int device, bool dedicated) {
         if (device < 0 || device >= 64) return nullptr;
         std::lock_guard<std::mutex> g(m);
-        if (idle[device].empty()) return nullptr;
-        hipStream_t s = idle[device].back();
-        idle[device].pop_back();
+        std::vector<hipStream_t>& v = idle[dedicated ? 1 : 0][device];
+        if (v.empty()) return nullptr;
+        hipStream_t s = v.back();
+        v.pop_back();
         return s;
     }
-    bool put(int device, hipStream_t s) noexcept {
+    bool put(int device, hipStream_t s, bool dedicated) noexcept {
         if (device < 0 || device >= 64) return false;
         try {
             std::lock_guard<std::mutex> g(m);
-            if (idle[device].size() >= 4) return false;
-            idle[device].push_back(s);
+            std::vector<hipStream_t>& v = idle[dedicated ? 1 : 0][device];
+            if (v.size() >= 4) return false;
+            v.push_back(s);
             return true;
         } catch (...) {
             return false;
@@ -712,27 +700,32 @@ int chain_stream_create(bmm_chain* c, bool dedicated) {
         e = hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest);
     } else if (mode == 2) {
-        uint32_t mask[16];
-        for (uint32_t& w : mask) w = 0xffffffffu;
-        const int cus = device_cus(c->device);
-        e = cus > 0 ? hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask) : hipErrorUnknown;
+        st = stream_pool().get(c->device, true);
+        if (st) {
+            e = hipSuccess;
+        } else {
+            uint32_t mask[16];
+            for (uint32_t& w : mask) w = 0xffffffffu;
+            const int cus = device_cus(c->device);
+            e = cus > 0 ? hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask) : hipErrorUnknown;
+        }
     }
-    bool plain = false;
+    int kind = mode == 2 ? 2 : 0;  // 0: not pooled, 1: a plain stream of the pool's kind, 2: one with its own queue
     if (e != hipSuccess) {  // mode 0, or the special stream could not be had
         (void)hipGetLastError();
-        st = stream_pool().get(c->device);
+        st = stream_pool().get(c->device, false);
         if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        plain = true;
+        kind = 1;
     }
     c->stream = st;
     c->dedicated_queue = dedicated;
-    c->plain_stream = plain;
+    c->stream_kind = kind;
     return BMM_OK;
 }
-// an idle plain stream goes back to the pool, anything else is destroyed
-void chain_stream_release(int device, hipStream_t st, bool plain) {
+// an idle stream goes back to the pool of its kind, anything else (and what the pool has no room for) is destroyed
+void chain_stream_release(int device, hipStream_t st, int kind) {
     if (!st) return;
-    if (plain && stream_pool().put(device, st)) return;
+    if (kind != 0 && stream_pool().put(device, st, kind == 2)) return;
     (void)hipStreamDestroy(st);
 }
 
@@ -743,11 +736,11 @@ int chain_dedicated_queue(bmm_chain* c) {
     if (c->dedicated_queue || c->started) return BMM_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t old = c->stream;
-    const bool old_plain = c->plain_stream;
+    const int old_kind = c->stream_kind;
     if (old) HIP_TRY(hipStreamSynchronize(old));
     int rc = chain_stream_create(c, true);
-    if (rc) { c->stream = old; c->plain_stream = old_plain; return rc; }
-    chain_stream_release(c->device, old, old_plain);
+    if (rc) { c->stream = old; c->stream_kind = old_kind; return rc; }
+    chain_stream_release(c->device, old, old_kind);
     return BMM_OK;
 }
 
@@ -784,6 +777,9 @@ int chain_alloc(bmm_chain* c) {
 #ifdef BMM_DIAG
         c->dDiag = a.take<unsigned long long>(16);
 #endif
+        c->dSelfDone = a.take<int>(1);
+        c->dDNkAlt = a.take<int32_t>(nn * kDeltaReps);
+        c->dDSAlt = a.take<int32_t>(ns * kDeltaReps);
 #ifdef BMM_DEBUG_HOOKS
         c->dDbgFlag = a.take<int>(1);
 #endif
@@ -826,10 +822,14 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
     ResampleArgs a{};
     a.X = c->dX; a.Xb = c->dXb; a.z_in = z_in; a.z_out = z_out; a.tab = c->dTab; a.dNk = c->dDNk; a.dS = c->dDS;
     a.lo = lo; a.hi = hi; a.sweep = sweep; a.minus_in_lds = c->minus_in_lds; a.diag = c->dDiag;
-    a.dbg_flag = c->dDbgFlag; a.dbg_inject = dbg_env("BMM_DEBUG_BADLABEL") != nullptr;
-    a.Nk = c->dNk; a.S = c->dS; a.alpha_ptr = c->dAlpha;
+    a.dbg_flag = c->dDbgFlag; a.dbg_inject = (dbg_env("BMM_DEBUG_BADLABEL") ? 1 : 0) | (dbg_env("BMM_DEBUG_STRAGGLER") ? 2 : 0);
+    a.Nk = c->dNk; a.S = c->dS; a.alpha_ptr = c->dAlpha; a.self_done = c->dSelfDone;
     const bool emit = c->probs_dst != nullptr;
     const bool use_generic = c->generic || (emit && !c->fn_emit);  // the int32 layout has no emitting twin
+    // a kernel that builds its own tables reads the pending deltas and flushes into the other (empty) set, which
+    // is the pending one from then on (self_fold_prev, kernels.hip.h)
+    const bool self_launch = c->self_tables && !emit && !use_generic;
+    if (self_launch) { a.dNk_prev = c->dDNk; a.dS_prev = c->dDS; a.dNk = c->dDNkAlt; a.dS = c->dDSAlt; }
     const int OT = emit ? c->NT_emit : c->OT, gmax = emit ? c->grid_max_emit : c->grid_max;
     const int64_t ntiles = use_generic ? 1 : (hi - lo + OT - 1) / OT;
     int grid = (int)(ntiles < gmax ? ntiles : gmax);
@@ -866,6 +866,7 @@ int launch_resample(bmm_chain* c, const int32_t* z_in, int32_t* z_out, int64_t l
         else hipLaunchKernelGGL(fn, dim3(grid), dim3(nt), lds, c->stream, c->p, a);
     }
     HIP_TRY(hipGetLastError());
+    if (self_launch) { std::swap(c->dDNk, c->dDNkAlt); std::swap(c->dDS, c->dDSAlt); }
     if (emit) {  // before the next k_count_tables rewrites the image's cluster sizes
         const int64_t nb = (hi - lo + 255) / 256;
         hipLaunchKernelGGL(k_probs_finish, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, c->stream, c->p,
@@ -953,8 +954,8 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
             if (dbl < len) len = dbl;
         }
         const int64_t hi = lo + len > p.N ? p.N : lo + len;
-        // (SELF kernels build their own image from S + the pending deltas; a sweep that hands its probabilities
-        // to the host runs the emitting twin, which reads the image k_count_tables writes)
+        // (SELF kernels build their own image from Nk, S and the previous launch's deltas; a sweep that hands its
+        // probabilities to the host runs the emitting twin, which reads the image k_count_tables writes)
         int rc = c->self_tables && !c->probs_dst ? BMM_OK : launch_count_tables(c);
         if (rc) return rc;
         rc = launch_resample(c, zin, zout, lo, hi, (uint32_t)j);
@@ -1110,7 +1111,7 @@ int bmm_last_run_phases(double* ms) {
 int bmm_host_threads(void) { return host_threads(); }
 
 // what the library keeps between calls -- up to eight 4 MiB pieces of pinned staging, and per device up to four
-// idle plain streams and up to 512 MiB of device blocks -- released now (a long-lived host process that is done
+// idle streams of either kind and up to 512 MiB of device blocks -- released now (a long-lived host process that is done
 // sampling)
 int bmm_release_pools(void) {
     {
@@ -1122,9 +1123,10 @@ int bmm_release_pools(void) {
     StreamPool& st = stream_pool();
     DevPool& dp = dev_pool();
     for (int d = 0; d < 64; ++d) {
-        std::vector<hipStream_t> idle;
+        std::vector<hipStream_t> idle, idle_q;
         std::vector<DevPool::Block> blocks;
-        { std::lock_guard<std::mutex> g(st.m); idle.swap(st.idle[d]); }
+        { std::lock_guard<std::mutex> g(st.m); idle.swap(st.idle[0][d]); idle_q.swap(st.idle[1][d]); }
+        idle.insert(idle.end(), idle_q.begin(), idle_q.end());
         { std::lock_guard<std::mutex> g(dp.m); blocks.swap(dp.idle[d]); }
         if (idle.empty() && blocks.empty()) continue;
         if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -1252,7 +1254,7 @@ void bmm_chain_destroy(bmm_chain* c) {
     void* bufs[] = {c->dX_owned, c->dScratch, c->dProbs, c->dWts, c->dWtot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    chain_stream_release(c->device, c->stream, c->plain_stream);  // synchronised above
+    chain_stream_release(c->device, c->stream, c->stream_kind);  // synchronised above
     delete c;
 }
 
@@ -1318,14 +1320,17 @@ int bmm_chain_set_data_host(bmm_chain* c, const int32_t* X) {
             for (int q = 0; q < 2; ++q) { HIP_TRY(own[q].alloc((size_t)slab * W * 4)); pin[q] = own[q].as<uint32_t>(); }
         EventPair done;
         HIP_TRY(done.create());
+        HostCrew crew;
+        std::vector<uint32_t*> plane((size_t)W);
         int64_t s = 0;
         for (int64_t i0 = 0; i0 < N; i0 += slab, ++s) {
             const int64_t rows = N - i0 < slab ? N - i0 : slab;
             uint32_t* const buf = pin[s & 1];
             if (s >= 2) HIP_TRY(hipEventSynchronize(done.e[s & 1]));  // its previous copy has left the buffer
             std::atomic<uint32_t> seen{0};
-            parallel_ranges(rows, 32768, 64, [&](int64_t lo, int64_t hi) {
-                seen.fetch_or(pack_rows_host(X, N, P, i0 + lo, i0 + hi, buf, slab, i0), std::memory_order_relaxed);
+            for (int w = 0; w < W; ++w) plane[(size_t)w] = buf + (int64_t)w * slab;
+            crew.run(rows, 32768, 64, [&](int64_t lo, int64_t hi) {
+                seen.fetch_or(pack_rows_host(X, N, P, i0 + lo, i0 + hi, plane.data(), i0), std::memory_order_relaxed);
             });
             if (seen.load() & ~1u) {
                 (void)hipStreamSynchronize(c->stream);
@@ -1795,6 +1800,34 @@ int run_sweeps_hooked(bmm_chain* c, int nsamples, const bmm_relabel_hooks* h) {
     return BMM_OK;
 }
 
+// One-byte labels widened into the caller's int32 trace (0 = unassigned -> NA_integer_), with streaming
+// stores: the destination is written once and not read again by this call, so its lines need not be fetched
+// first (that read-for-ownership doubles the memory traffic of a plain store loop).
+void widen_labels(const uint8_t* src, int32_t* dst, int64_t n) {
+    int64_t q = 0;
+    for (; q < n && (reinterpret_cast<uintptr_t>(dst + q) & 15); ++q) dst[q] = src[q] ? (int32_t)src[q] : BMM_NA_INTEGER;
+    const __m128i zero = _mm_setzero_si128(), na = _mm_set1_epi32(BMM_NA_INTEGER);
+    for (; q + 16 <= n; q += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + q));
+        const __m128i lo = _mm_unpacklo_epi8(v, zero), hi = _mm_unpackhi_epi8(v, zero);
+        __m128i w[4] = {_mm_unpacklo_epi16(lo, zero), _mm_unpackhi_epi16(lo, zero), _mm_unpacklo_epi16(hi, zero), _mm_unpackhi_epi16(hi, zero)};
+        for (int k = 0; k < 4; ++k) {
+            w[k] = _mm_or_si128(w[k], _mm_and_si128(_mm_cmpeq_epi32(w[k], zero), na));
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + q + 4 * k), w[k]);
+        }
+    }
+    for (; q < n; ++q) dst[q] = src[q] ? (int32_t)src[q] : BMM_NA_INTEGER;
+    _mm_sfence();
+}
+void copy_labels(const int32_t* src, int32_t* dst, int64_t n) {  // the same for labels that travel as int32
+    int64_t q = 0;
+    for (; q < n && (reinterpret_cast<uintptr_t>(dst + q) & 15); ++q) dst[q] = src[q];
+    for (; q + 4 <= n; q += 4)
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst + q), _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + q)));
+    for (; q < n; ++q) dst[q] = src[q];
+    _mm_sfence();
+}
+
 // The label trace out to the caller's S x N column-major matrix (labels 1-based, NA where unassigned).
 // In that layout the S labels of one observation are contiguous, so a block of observations is a contiguous
 // run of the caller's buffer: the device transposes the [S][N] trace block by block (k_trace_block), each
@@ -1819,20 +1852,19 @@ int trace_out(bmm_chain* c, int32_t* z_out, PhaseClock* clock) {
         for (int q = 0; q < 2; ++q) { HIP_TRY(own[q].alloc(blk_bytes)); hblk[q] = own[q].p; }
     EventPair ev;
     HIP_TRY(ev.create());
+    std::unique_ptr<HostCrew> own_crew;  // a resident chain's trace (no *_run call around it)
+    HostCrew* crew = c->crew;
+    if (!crew) { own_crew.reset(new HostCrew()); crew = own_crew.get(); }
     auto consume = [&](int64_t blk) {
         const int64_t i0 = blk * B, rows = N - i0 < B ? N - i0 : B;
         int32_t* const dst = z_out + (size_t)i0 * S;
         const int64_t n = rows * S;
         if (narrow) {
             const uint8_t* const src = static_cast<const uint8_t*>(hblk[blk & 1]);
-            parallel_ranges(n, 1 << 18, 64, [&](int64_t lo, int64_t hi) {
-                for (int64_t q = lo; q < hi; ++q) dst[q] = src[q] ? (int32_t)src[q] : BMM_NA_INTEGER;
-            });
+            crew->run(n, 1 << 16, 64, [=](int64_t lo, int64_t hi) { widen_labels(src + lo, dst + lo, hi - lo); });
         } else {
             const int32_t* const src = static_cast<const int32_t*>(hblk[blk & 1]);
-            parallel_ranges(n, 1 << 18, 64, [&](int64_t lo, int64_t hi) {
-                std::memcpy(dst + lo, src + lo, (size_t)(hi - lo) * sizeof(int32_t));
-            });
+            crew->run(n, 1 << 16, 64, [=](int64_t lo, int64_t hi) { copy_labels(src + lo, dst + lo, hi - lo); });
         }
     };
     const int64_t nblk = (N + B - 1) / B;
@@ -1937,17 +1969,48 @@ int run_body(bmm_chain* c, int nsamples, const RunIO& io, const bmm_relabel_hook
     return dbg_labels_ok(c);
 }
 
-// planes packed on the host (AsyncPack: [w][N] in ordinary memory) into the chain: one upload
-int chain_set_planes_host(bmm_chain* c, const uint32_t* words) {
+// planes packed on the host (AsyncPack: one pointer per plane, pinned pieces or ordinary memory) into the chain
+int chain_set_planes_host(bmm_chain* c, uint32_t* const* plane) {
     const int W = (c->p.P + 31) / 32;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->dXb) { int rcp = planes_alloc(c, (size_t)W * c->p.N); if (rcp) return rcp; }
-    HIP_TRY(hipMemcpyAsync(c->dXb, words, (size_t)W * c->p.N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    for (int w = 0; w < W; ++w)
+        HIP_TRY(hipMemcpyAsync(c->dXb + (size_t)w * c->p.N, plane[w], (size_t)c->p.N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dX = nullptr;
     c->have_data = true;
     return BMM_OK;
 }
+
+#ifdef BMM_DEBUG_HOOKS
+// Test variant only: the host-side ends of a run on their own, no device involved (tests/test_capi_cpu.py
+// holds them to numpy): X packed into planes [w][N] by the crew, and a block of one-byte / int32 labels
+// copied into an int32 trace.
+extern "C" int bmm_dbg_host_pack(const int32_t* X, int64_t N, int P, uint32_t* out, uint32_t* seen_out) {
+    return guarded([&]() -> int {
+        const int W = (P + 31) / 32;
+        std::vector<uint32_t*> plane((size_t)W);
+        for (int w = 0; w < W; ++w) plane[(size_t)w] = out + (size_t)w * (size_t)N;
+        std::atomic<uint32_t> seen{0};
+        HostCrew crew;
+        crew.run(N, 1024, 64, [&](int64_t lo, int64_t hi) {
+            seen.fetch_or(pack_rows_host(X, N, P, lo, hi, plane.data(), 0), std::memory_order_relaxed);
+        });
+        *seen_out = seen.load();
+        return BMM_OK;
+    });
+}
+extern "C" int bmm_dbg_host_labels(const void* src, int narrow, int32_t* dst, int64_t n, int jobs) {
+    return guarded([&]() -> int {
+        HostCrew crew;
+        for (int j = 0; j < jobs; ++j) {  // the same crew, job after job, as trace_out uses it
+            if (narrow) crew.run(n, 256, 64, [=](int64_t lo, int64_t hi) { widen_labels(static_cast<const uint8_t*>(src) + lo, dst + lo, hi - lo); });
+            else crew.run(n, 256, 64, [=](int64_t lo, int64_t hi) { copy_labels(static_cast<const int32_t*>(src) + lo, dst + lo, hi - lo); });
+        }
+        return BMM_OK;
+    });
+}
+#endif
 
 int check_run_args(const int32_t* X, int nsamples, int burnin, const RunIO& io, int sampler) {
     if (!X || !io.z_out || !io.theta_out || !io.alpha_out) return set_err(BMM_E_ARG, "null buffer");
@@ -1970,12 +2033,14 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int
         // thread creates the chain, allocates the run's buffers and uploads the starting state: the two take
         // about as long at the north-star shape, and only the planes -- 4 * ceil(P/32) bytes per observation
         // instead of 4 * P -- then cross PCIe.
+        HostCrew crew;  // the host threads of this call: they pack X now and widen the label trace at the end
         AsyncPack pack;
         const bool host_pack = dbg_env("BMM_X_LAYOUT_INT32") == nullptr;
-        if (host_pack) pack.start(X, N, P);
+        if (host_pack) pack.start(&crew, X, N, P);
         bmm_chain* c = nullptr;
         rc = bmm_chain_create(&c, sampler, N, P, K, alpha, beta, gamma, a, b, batch, seed, device);
         if (rc) return rc;
+        c->crew = &crew;
         {
             struct Guard { bmm_chain* c; ~Guard() { bmm_chain_destroy(c); } } guard{c};
             rc = run_prepare(c, nsamples, burnin);
@@ -1983,12 +2048,12 @@ int run_chain(int sampler, const int32_t* X, int64_t N, int P, int nsamples, int
             if (rc) return rc;
             clock.lap(1);
             pack.join();
-            if (host_pack && c->bits && pack.failed.load() == 0) {
+            if (host_pack && c->bits) {
                 if (pack.seen.load() & ~1u) return set_err(BMM_E_ARG, "data must be binary: X holds a value other than 0 and 1");
-                rc = chain_set_planes_host(c, pack.words.get());
-                pack.words.reset();
-            } else {  // the int32 layout (test variant), or the workers could not be started: the resident API's way
-                pack.words.reset();
+                rc = chain_set_planes_host(c, pack.plane.data());
+                pack.release();
+            } else {  // the int32 layout (test variant): the resident API's way
+                pack.release();
                 rc = bmm_chain_set_data_host(c, X);
             }
             if (rc) return rc;

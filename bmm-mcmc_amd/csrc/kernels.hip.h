@@ -470,10 +470,15 @@ struct ResampleArgs {
     unsigned long long* diag;  // BMM_DIAG builds: [5] cycle sums (score, pack, draw, movers, prologue)
     int* dbg_flag;         // -DBMM_DEBUG_HOOKS builds: set when a kernel meets a label outside its range
     int dbg_inject;        //   ... and a test's way to make one (BMM_DEBUG_BADLABEL)
-    // SELF kernels (workgroups that build their own table image): the folded statistics and the concentration
-    const int32_t* Nk;
-    const int32_t* S;
+    // SELF kernels (workgroups that build their own table image): the folded statistics, the deltas the previous
+    // launch left (dNk / dS above are the set this launch flushes into), the concentration, and the count of
+    // workgroups that have read all of that (self_fold_prev)
+    int32_t* Nk;
+    int32_t* S;
+    int32_t* dNk_prev;
+    int32_t* dS_prev;
     const double* alpha_ptr;
+    int* self_done;
 };
 
 // The test variant of the library (-DBMM_DEBUG_HOOKS) checks every label a resample kernel is about to count
@@ -483,7 +488,7 @@ struct ResampleArgs {
 // observation is left unassigned and uncounted.  The product build carries none of this.
 #ifdef BMM_DEBUG_HOOKS
 __device__ __forceinline__ void dbg_check_labels(const ResampleArgs& a, bool valid, bool first, int K, int& zn, int& zo) {
-    if (a.dbg_inject && valid && first) zn = K + 3;
+    if ((a.dbg_inject & 1) && valid && first) zn = K + 3;
     if (valid && (zn < 0 || zn >= K || zo < -1 || zo >= K)) {
         atomicOr(a.dbg_flag, 1);
         zn = -1; zo = -1;
@@ -752,18 +757,45 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 // logs costs a launch about 2 us, and from the third on the table launch it replaces was cheaper).  Such shapes are bound by launches, not by work: a sweep of config 2
 // is 8 table launches + 8 resample launches + 1, each a few microseconds, and this form drops the 8 table launches
 // (every workgroup of a launch building the image of a bigger shape itself was measured in round 2: 8 000 logs per
-// workgroup cost six times what the launch did).  The statistics are not folded between batches then: a workgroup
-// reads S + the pending deltas; k_count_sweep_end folds at the end of the sweep as before.  Same functions, same
-// operands, same order as k_count_tables and write_group_tables: the image is bit-identical.
+// workgroup cost six times what the launch did).  The statistics are then folded by one of the launch's own
+// workgroups (self_fold_prev, below).  Same functions, same operands, same order as k_count_tables and write_group_tables: the
+// image is bit-identical.
 // scratch (LDS, doubles): terms [K][4][P] (x=1 / x=0 against the full statistics, then with the scored
 // observation removed), logs [K][8], consts [KT][2] (Cp, Cm).
 __host__ __device__ inline size_t self_scratch_doubles(int K, int KT, int P) { return (size_t)K * 4 * P + (size_t)K * 8 + (size_t)KT * 2; }
 __host__ __device__ inline bool self_tables_fit(int mode, int K, int P, int threads) {
     return mode == MODE_COLLAPSED && P <= kChunkP && (long)K * (4 * P + 5) <= 2L * threads;
 }
+// SELF kernels read the statistics themselves when a workgroup starts -- Nk, S and the deltas of the previous
+// launch -- so all three must stay as the previous launch left them until every workgroup of THIS launch has
+// read them: a workgroup may start late (another chain's kernels on the device, another process), after others
+// of its launch have already finished and flushed.  Two sets of delta accumulators therefore take turns: a
+// launch flushes into the one that is empty and reads the other; each workgroup takes a ticket (a counter in
+// global memory) once its reads are done, and the one that draws the last ticket -- nobody will read the old
+// values again -- folds the previous launch's deltas into Nk and S and clears them, while the others are already
+// scoring.  The host swaps the two sets after every such launch, so that to every other kernel (k_count_tables
+// in a sweep that emits probabilities, k_count_sweep_end, the accessors) "the deltas" are the pending set as
+// before and the other set is zero.  Integer sums: the result does not depend on who folds or when.
+template <int NT>
+__device__ __forceinline__ void self_fold_prev(const ResampleArgs& a, int K, int P, int tid) {
+    const int KP = K * P;
+    for (int i = tid; i < KP + K; i += NT) {
+        if (i < KP) {
+            const int32_t v = delta_take(a.dS_prev, (size_t)i, (size_t)KP);
+            if (v != 0) a.S[i] += v;
+            delta_clear(a.dS_prev, (size_t)i, (size_t)KP);
+        } else {
+            const int32_t v = delta_take(a.dNk_prev, (size_t)(i - KP), (size_t)K);
+            if (v != 0) a.Nk[i - KP] += v;
+            delta_clear(a.dNk_prev, (size_t)(i - KP), (size_t)K);
+        }
+    }
+    if (tid == 0) *a.self_done = 0;  // every ticket of this launch has been drawn
+}
+
 template <int KT, int NT, int GW>
 __device__ __forceinline__ void build_tables_self(const ChainParams& p, const ResampleArgs& a, const TableLayout& L,
-                                                  double* lds, double* scratch, int tid) {
+                                                  double* lds, double* scratch, int tid, int* is_last) {
     constexpr int GM = 1 << GW;
     const int K = p.K, P = p.P;
     const size_t KP = (size_t)K * P;
@@ -784,8 +816,8 @@ __device__ __forceinline__ void build_tables_self(const ChainParams& p, const Re
         raw[q] = 0.0; have[q] = false;
         if (t < nterm) {
             const int k = t / (4 * P), role = (t / P) & 3, d = t % P;
-            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
-            const int32_t sd = a.S[(size_t)k * P + d] + delta_take(a.dS, (size_t)k * P + d, KP);
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk_prev, k, K);
+            const int32_t sd = a.S[(size_t)k * P + d] + delta_take(a.dS_prev, (size_t)k * P + d, KP);
             // term_x1 / term_x0 of bmm_spec.h as k_count_tables evaluates them, the denominator subtracted below
             if (role == 0) { have[q] = n > 0; raw[q] = have[q] ? log_(p.beta + (double)sd) : 0.0; }
             else if (role == 1) { have[q] = n > 0; raw[q] = have[q] ? log_((p.gamma + (double)n) - (double)sd) : 0.0; }
@@ -793,7 +825,7 @@ __device__ __forceinline__ void build_tables_self(const ChainParams& p, const Re
             else { have[q] = n > 1 && sd <= n - 1; raw[q] = have[q] ? log_((p.gamma + (double)(n - 1)) - (double)sd) : 0.0; }
         } else if (t < nitem) {
             const int k = (t - nterm) / 5, lane = (t - nterm) % 5;
-            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk_prev, k, K);
             double arg = 1.0;
             bool need = false;
             switch (lane) {  // the logs of k_count_tables' ninth wave, lanes 0-4 (5-7 belong to the DP's new cluster)
@@ -821,7 +853,7 @@ __device__ __forceinline__ void build_tables_self(const ChainParams& p, const Re
         double cp = neg_inf(), cm = neg_inf();
         int32_t n32 = 0;
         if (k < K) {
-            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk, k, K);
+            const int64_t n = (int64_t)a.Nk[k] + delta_take(a.dNk_prev, k, K);
             const double* v = logs + (size_t)k * 8;
             if (n > 0) cp = v[2] - v[4];
             if (n > 1) cm = v[3] - v[4];
@@ -833,6 +865,9 @@ __device__ __forceinline__ void build_tables_self(const ChainParams& p, const Re
         reinterpret_cast<int32_t*>(lds + L.nk())[k] = n32;
     }
     __syncthreads();
+    // every read of the statistics is done: the ticket (self_fold_prev); its answer is needed only after phase C
+    int ticket = 0;
+    if (tid == 0) ticket = atomicAdd(a.self_done, 1);
     // phase C: the group tables, laid out as write_group_tables lays them out (constant folded into group 0;
     // accumulators past K score -inf; the own-cluster tables padded with zero groups)
     for (int idx = tid; idx < L.G * KT * GM; idx += NT) {
@@ -852,6 +887,7 @@ __device__ __forceinline__ void build_tables_self(const ChainParams& p, const Re
         }
         lds[L.tm() + ((size_t)g * KT + k) * kGroupMm + m] = v;
     }
+    if (tid == 0) *is_last = ticket == (int)gridDim.x - 1;
     for (int i = tid; i < 256; i += NT) lds[L.et() + i] = exp256_table()[i];
 }
 
@@ -933,9 +969,15 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
         else issue_stage<STG>(pos, p.N, P, 0, st);
     }
     if (SELF) {
+#ifdef BMM_DEBUG_HOOKS
+        // test variant, BMM_DEBUG_STRAGGLER: workgroup 0 starts about 100 us late, as it may on a device that other
+        // work shares -- the others have flushed by then (tests/test_gpu_layouts.py)
+        if ((a.dbg_inject & 2) && blockIdx.x == 0)
+            for (int i = 0; i < 30; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
         // behind the histogram (and its chunk counter), on an 8-byte boundary
         double* const scratch = lds + lds_doubles + ((size_t)(K * P + K + 4) * sizeof(int32_t) + 7) / 8;
-        build_tables_self<KT, NT, GW>(p, a, L, lds, scratch, tid);
+        build_tables_self<KT, NT, GW>(p, a, L, lds, scratch, tid, next_chunk + 1);  // (a spare word behind the counter)
     } else {
         // stage the table image: eight 16-byte loads in flight per lane (one L2 round trip per
         // eight, not per one)
@@ -959,6 +1001,7 @@ __global__ __launch_bounds__(NT) void k_resample(ChainParams p, ResampleArgs a) 
     for (int i = tid; i < K * P + K; i += NT) hist[i] = 0;
     if (tid == 0) *next_chunk = NW;  // chunks 0 .. NW-1 of the workgroup are the waves' first ones
     __syncthreads();
+    if (SELF && next_chunk[1]) self_fold_prev<NT>(a, K, P, tid);  // this workgroup was the last to read the statistics
 
     // DP bookkeeping shared by the whole batch (collapsed_gibbs_dp.cpp:166-171,212-231)
     int Kused = 0, new_label = -1;

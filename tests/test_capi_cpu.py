@@ -145,3 +145,63 @@ def test_multi_run_placement_is_pure_bookkeeping():
     rc, _, _ = plan([0, -1])
     assert rc == 1 and b"devices[1]" in L.bmm_last_error()
     assert L.bmm_multi_plan(C.c_int(0), None, None, None, None) == 1
+
+
+# ---- the host-side ends of a *_run call, without a device (test-variant exports of the debug-hooks build)
+def _dbg_cdll():
+    import ctypes
+    from bmm_mcmc_amd import build
+    if build.stale(build.LIB_DBG):
+        build.build(debug_variant=True)
+    return ctypes.CDLL(build.LIB_DBG)
+
+
+@pytest.mark.parametrize("N,P", [(1, 1), (63, 7), (4097, 32), (70001, 50), (33000, 100), (5000, 129)])
+def test_host_pack_equals_numpy_bit_planes(N, P):
+    """what the host's threads make of R's column-major int32 matrix: feature d at bit d % 32 of word d / 32, planes
+    [w][N], bits past P zero -- the layout k_pack_bits writes on the device (tests/test_gpu_fullsize.py holds
+    the two to each other through a chain)"""
+    import ctypes
+    lib = _dbg_cdll()
+    rng = np.random.default_rng(N + P)
+    X = np.asfortranarray((rng.random((N, P)) < 0.4).astype(np.int32))
+    W = (P + 31) // 32
+    out = np.full((W, N), 0xFFFFFFFF, dtype=np.uint32)
+    seen = ctypes.c_uint32(7)
+    rc = lib.bmm_dbg_host_pack(X.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(N), ctypes.c_int(P),
+                               out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(seen))
+    assert rc == 0 and seen.value == int(X.max())
+    want = np.zeros((W, N), dtype=np.uint32)
+    for d in range(P):
+        want[d // 32] |= X[:, d].astype(np.uint32) << np.uint32(d % 32)
+    np.testing.assert_array_equal(out, want)
+    # a cell that is not 0/1 shows in the OR the caller checks
+    X[N // 2, P - 1] = 6
+    lib.bmm_dbg_host_pack(X.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(N), ctypes.c_int(P),
+                          out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(seen))
+    assert seen.value & ~1
+
+
+@pytest.mark.parametrize("n,offset", [(0, 0), (1, 0), (15, 1), (16, 0), (1000, 3), (262147, 1), (1 << 20, 0)])
+def test_host_label_copies_widen_and_mark_unassigned(n, offset):
+    """trace_out's host half: one-byte labels (0 = unassigned) widened to R's int32 with NA_integer_, int32 labels
+    copied as they are; destinations that do not start on a 16-byte boundary, lengths that are no multiple of
+    the vector width, and the same threads reused job after job"""
+    import ctypes
+    lib = _dbg_cdll()
+    rng = np.random.default_rng(n + offset)
+    NA = -2147483648
+    src8 = rng.integers(0, 255, size=n, dtype=np.uint8)
+    if n > 4:
+        src8[:3] = (0, 254, 1)
+    buf = np.full(n + 8, 12345, dtype=np.int32)
+    dst = buf[offset:offset + n]
+    assert lib.bmm_dbg_host_labels(src8.ctypes.data_as(ctypes.c_void_p), 1, dst.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), 3) == 0
+    want = src8.astype(np.int32)
+    want[src8 == 0] = NA
+    np.testing.assert_array_equal(dst, want)
+    assert (buf[:offset] == 12345).all() and (buf[offset + n:] == 12345).all()
+    src32 = rng.integers(1, 400, size=n, dtype=np.int32)
+    assert lib.bmm_dbg_host_labels(src32.ctypes.data_as(ctypes.c_void_p), 0, dst.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), 2) == 0
+    np.testing.assert_array_equal(dst, src32)
+    assert (buf[:offset] == 12345).all() and (buf[offset + n:] == 12345).all()

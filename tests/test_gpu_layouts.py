@@ -190,3 +190,27 @@ def test_self_built_tables_equal_the_table_kernels(oracle, dbg_lib, noself):
     assert np.array_equal(z, want["z"][0])
     np.testing.assert_allclose(probs.sum(axis=1), 1.0, rtol=0, atol=1e-14)
     assert shape["threads"] == 256
+
+
+def test_self_built_tables_with_a_workgroup_that_starts_late(oracle, dbg_lib):
+    """A workgroup of a table-building launch may start after others of the same launch have finished -- the device
+    is shared with another chain's kernels, or another process -- and must still score against the statistics as the
+    PREVIOUS launch left them.  BMM_DEBUG_STRAGGLER (test variant) holds workgroup 0 back by about 100 us, long after
+    the other workgroups of these short launches have flushed their counts.  (Round 3 first read the statistics plus
+    the pending deltas in every workgroup: a late one then saw part of its own launch -- found as a one-in-twenty
+    mismatch of a chain that ran beside two others, tests/test_gpu_multi.py.)"""
+    dbg_lib.setenv("BMM_DEBUG_STRAGGLER", "1")
+    dbg_lib.delenv("BMM_DEBUG_NOSELF", raising=False)
+    for N, P, K, batch in [(100000, 20, 3, 12500), (20000, 24, 3, 2048), (5000, 24, 3, 512)]:
+        X, _, _, _ = synth(N, P, K, N + P)
+        z0 = _z0(N, K, 3)
+        with bm.Chain("collapsed", N, P, K, batch=batch, seed=5) as ch:
+            ch.set_data(X)
+            ch.set_initial_labels(z0)
+            ch.sweeps(4)
+            z, (nk, S), shape = ch.labels(), ch.counts(), ch.kernel_shape()
+        assert shape["threads"] == 256                  # the table-building kernels
+        want = oracle.collapsed(X, z0, 5, K, 0.0, 0.5, 0.5, 1, 1, 4, seed=5, batch=batch)
+        assert np.array_equal(z, want["z"][0]), (N, P, K, batch, int((z != want["z"][0]).sum()))
+        assert np.array_equal(nk, np.bincount(z - 1, minlength=K))
+        assert np.array_equal(S, np.stack([X[z == k + 1].sum(axis=0) for k in range(K)]))

@@ -14,17 +14,20 @@ from bmm_mcmc_amd import _capi, synth
 
 SHAPES = {"ns": (1_000_000, 50, 20, 22, 220, 200), "c5": (10_000_000, 100, 20, 21, 30, 3),
           "c2": (100_000, 20, 3, 18, 1000, 100)}
-PH = ("create+upload", "start state", "enqueue", "device wait", "trace out", "release")
+PH = ("pack left+upload", "create+start state", "enqueue", "device wait", "trace out", "release")
 
 
-def probe(name, reps=3):
+def probe(name, reps=int(os.environ.get("REPS", "6"))):
     N, P, K, dseed, ns, burn = SHAPES[name]
     X, _, _, _ = synth.host_matrix(N, P, K, dseed)
     z0 = np.random.default_rng(0).integers(1, K + 1, N).astype(np.int32)
     S = ns - burn
     L = _capi.lib()
     print("%s: N=%d P=%d K=%d nsamples=%d kept=%d, host threads %d" % (name, N, P, K, ns, S, L.bmm_host_threads()))
+    keep = []
     for rep in range(reps):
+        if os.environ.get("KEEP"):
+            keep.append((locals().get("z"), locals().get("th"), locals().get("al"), locals().get("out")))
         z = np.empty((S, N), dtype=np.int32, order="F")   # as R's allocMatrix: untouched pages
         th = np.empty((K, P, S), order="F")
         al = np.empty((S, 1), order="F")
@@ -37,6 +40,9 @@ def probe(name, reps=3):
         ms = (C.c_double * 6)()
         L.bmm_last_run_phases(ms)
         print("  rep %d: %.1f ms = %.0f sweeps/s | " % (rep, 1e3 * dt, ns / dt) + ", ".join("%s %.1f" % (n, v) for n, v in zip(PH, ms)))
+        if os.environ.get("NO_WRAPPER"):
+            continue
+        out = None   # the previous result is released outside the clock
         t0 = time.perf_counter()
         out = bm.gibbs_collapsed(X, ns, K, burnin=burn, seed=1, initial_K=z0)
         print("         through the Python wrapper: %.1f ms" % (1e3 * (time.perf_counter() - t0)))
