@@ -11,8 +11,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = {
     # name: sampler, K (or maxK), K_true, N, P, data seed, burnin, kept, inits
     "ns": ("collapsed", 20, 20, 1_000_000, 50, 22, 40, 100, ("truth", "random")),
-    "nsq": ("collapsed", 20, 20, 262_144, 50, 24, 40, 100, ("truth", "random")),  # the smallest N whose default batch is N/4
+    "nsq": ("collapsed", 20, 20, 262_144, 50, 24, 40, 100, ("truth", "random")),
     "nsb": ("collapsed", 20, 20, 524_288, 50, 23, 40, 100, ("truth", "random")),
+    "nse5": ("collapsed", 20, 20, 100_000, 50, 25, 40, 100, ("truth", "random")),
+    "nse16": ("collapsed", 20, 20, 65_536, 50, 26, 40, 100, ("truth", "random")),   # the smallest N whose default batch is N/4
     "c2": ("collapsed", 3, 3, 100_000, 20, 18, 100, 200, ("truth", "random")),
     "c5s": ("collapsed", 20, 20, 2_000_000, 100, 21, 40, 100, ("truth", "random")),
     "c5": ("collapsed", 20, 20, 10_000_000, 100, 21, 40, 100, ("truth", "random")),
