@@ -984,10 +984,12 @@ int pick_kernel(bmm_chain* c) {
     // (the north-star shape: 15 us per launch of which 4 are arithmetic, VALU busy 27 %), and the two-lane
     // form halves the chain of dependent work per wave (half the categories to score, to exponentiate and
     // to compare per lane) at the same number of workgroups.  Same draw, bit for bit.
-    const int64_t chunks = (c->batch + 63) / 64;
+    // "Short" = the batch cannot give every CU a one-lane workgroup of 768 threads (196 608 observations on 256
+    // CUs): below that the one-lane form steps down to 512 threads and two waves per SIMD.  Same-box, north-star
+    // shape by batch: 125 000 two-lane +11 %, 162 500 +11 %, 200 000 -2.5 %, 250 000 -8 % (profiles/r03/ab_smallsplit.log).
     // (not for chains that share their device: several chains' launches fill the chip between them, and then
     // the one-lane form's lower total work wins -- four north-star chains: 14.8 k against 12.1 k sweeps/s)
-    const bool short_launch = BMM_SMALL_SPLIT && !c->shares_device && p.KT >= 16 && !alt && chunks < (int64_t)c->num_cus * 24;
+    const bool short_launch = BMM_SMALL_SPLIT && !c->shares_device && p.KT >= 16 && !alt && c->batch < (int64_t)c->num_cus * kThreadsMid;
     if (c->bits && (p.KT > 32 || short_launch) && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
         if (resample_fn f = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W)) {
             c->fn = f;
