@@ -590,11 +590,11 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
 // Default batch -- a pure function of (sampler, N): no device, occupancy or layout enters, so a defaulted batch
 // names the same chain everywhere.  Below 2^16 observations: floor(N/8) for the finite sampler, floor(N/16) for the
 // DP sampler (above that every "new" draw of a batch shares one label and spurious clusters open on small data).
-// From 2^16 observations on: floor(N/4) and floor(N/8).  The bias of a batch against the sequential scan shrinks
+// From 2^16 observations on: floor(N/4) for both.  The bias of a batch against the sequential scan shrinks
 // with N -- the net flow into a cluster during a batch is O(sqrt N), its size O(N) -- and at those sizes it is not
 // measurable: the committed batch-1 fixtures (tests/golden/tolerance_*.json; K = 20 at N = 2^16, 1e5, 2^18, 2^19, 1e6, 2e6
-// and 1e7, K = 3 at 1e5, five DP shapes from N = 1e5) are met to 2e-5 in the proportions and 1e-3 in theta-hat at N/4 as at N/8, and
-// the DP's clusters per generating component at N/8 as at N/16 (tests/test_gpu_tolerance_fixtures.py runs at
+// and 1e7, K = 3 at 1e5, seven DP shapes from N = 2^16) are met to 2e-5 in the proportions and 1e-3 in theta-hat at N/4 as at
+// N/8, and the DP's shares per generating component and cluster counts at N/4 as at N/16 (tests/test_gpu_tolerance_fixtures.py runs at
 // whatever this function returns; profiles/r03/README.md has the numbers, including that a random start ends in the
 // generating mode as often at N/4 as at N/8).  What a larger batch buys is launches: a batch costs about 20 us of
 // fixed time whatever its size (k_count_tables + the resample launch's own set-up and flush).
@@ -603,7 +603,7 @@ int validate_binary(bmm_chain* c, const int32_t* dX, int64_t n) {
 constexpr int64_t kLargeN = (int64_t)1 << 16;
 int64_t default_batch(int sampler, int64_t N) {
     if (sampler == BMM_SAMPLER_SB || sampler == BMM_SAMPLER_FULL) return N;
-    const int64_t div = (sampler == BMM_SAMPLER_DP ? 16 : 8) / (N >= kLargeN ? 2 : 1);
+    const int64_t div = N >= kLargeN ? 4 : (sampler == BMM_SAMPLER_DP ? 16 : 8);
     const int64_t b = N / div;
     return b < 1 ? 1 : b;
 }

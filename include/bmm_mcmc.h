@@ -49,7 +49,7 @@
  * allocation (the bias of a batch shrinks with N; the bundled N <= 1000 sets above are the hard case).  For the
  * DP sampler there the quantity is the share of the observations per generating component (the sequential
  * scan itself seats a generating component as two clusters at N >= 1e5).  The tests run at exactly what
- * bmm_default_batch returns (N/8 and N/16 below 2^16 observations, N/4 and N/8 from there on), including a
+ * bmm_default_batch returns (N/8 and N/16 below 2^16 observations, N/4 for both samplers from there on), including a
  * K = 20 fixture at N = 2^16, the smallest N that gets the larger batch.
  * The stick-breaking and full samplers have no batch and no tolerance:
  * their z-step is exactly parallel (src/stickbreaking.cpp:69-92 reads only sweep j-1).
@@ -91,8 +91,8 @@ int bmm_spec_group_width(void);
 int bmm_spec_group_width_own(void);
 int bmm_spec_group_width_for(int sampler, int K, int P);
 /* library default batch size for N observations (used when batch <= 0): below 2^16 observations floor(N/8)
- * for the finite sampler and floor(N/16) for the DP sampler (at least 1); from 2^16 on floor(N/4) and
- * floor(N/8) -- the bias of a batch shrinks with N and is not measurable there (TOLERANCE above; DESIGN.md
+ * for the finite sampler and floor(N/16) for the DP sampler (at least 1); from 2^16 on floor(N/4) for
+ * both -- the bias of a batch shrinks with N and is not measurable there (TOLERANCE above; DESIGN.md
  * section 2); N for stick-breaking and full.  Depends on nothing else. */
 int64_t bmm_default_batch(int sampler, int64_t N);
 

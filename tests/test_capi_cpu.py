@@ -36,17 +36,17 @@ def test_spec_constants_match_oracle(oracle):
 def test_default_batch_policy():
     assert bm.default_batch("stickbreaking", 1000) == 1000
     assert bm.default_batch("collapsed", 100) == 12
-    # a pure function of (sampler, N): floor(N/8) (N/16 dp) below 2^16 observations, floor(N/4) (N/8 dp) from there
+    # a pure function of (sampler, N): floor(N/8) (N/16 dp) below 2^16 observations, floor(N/4) from there
     # on, at least 1, never rounded -- the ratios the tolerance fixtures are held at
-    assert bm.default_batch("collapsed", 10 ** 7) == 2_500_000 and bm.default_batch("dp", 10 ** 7) == 1_250_000
+    assert bm.default_batch("collapsed", 10 ** 7) == 2_500_000 and bm.default_batch("dp", 10 ** 7) == 2_500_000
     for N in (1, 7, 100, 12345, 2 ** 16 - 1):
         assert bm.default_batch("collapsed", N) == max(1, N // 8)
         assert bm.default_batch("dp", N) == max(1, N // 16)
     for N in (2 ** 16, 10 ** 5, 4 * 10 ** 5, 10 ** 6, 8 * 3 * 2 ** 18 + 8, 2 ** 31 + 5):
         assert bm.default_batch("collapsed", N) == N // 4
-        assert bm.default_batch("dp", N) == N // 8
+        assert bm.default_batch("dp", N) == N // 4
     assert bm.default_batch("collapsed", 10 ** 6) == 250000
-    assert bm.default_batch("dp", 10 ** 6) == 125000
+    assert bm.default_batch("dp", 10 ** 6) == 250000
     assert bm.default_batch("dp", 1600) == 100
     assert bm.default_batch("dp", 3) == 1
     assert bm.default_batch("full", 77) == 77

@@ -126,7 +126,7 @@ def test_host_matrix_uploaded_in_slabs_equals_the_device_matrix_packed_at_once()
 @pytest.mark.timeout(600)
 def test_posterior_recovers_the_generating_mixture_at_the_default_batch():
     """North-star acceptance on cluster proportions, at sizes the oracle cannot reach: with the default
-    batch (N/4, N/8 for the DP sampler, at these sizes: bmm_default_batch) the chain must find the mixture the synthetic data were drawn
+    batch (N/4 at these sizes: bmm_default_batch) the chain must find the mixture the synthetic data were drawn
     from -- posterior-mean proportions within 0.01 of the generating weights, a draw of the labels
     agreeing with the generating ones (up to a permutation) as often as a draw from the exact posterior
     under the generating parameters would (within one point).  The DP sampler may hold a generating

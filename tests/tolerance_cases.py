@@ -18,6 +18,8 @@ CASES = {
     "c2": ("collapsed", 3, 3, 100_000, 20, 18, 100, 200, ("truth", "random")),
     "c5s": ("collapsed", 20, 20, 2_000_000, 100, 21, 40, 100, ("truth", "random")),
     "c5": ("collapsed", 20, 20, 10_000_000, 100, 21, 40, 100, ("truth", "random")),
+    "dp5_e16": ("dp", 30, 5, 65_536, 50, 79, 150, 100, ("empty",)),     # the smallest N whose default batch is N/4
+    "dp10_e16": ("dp", 30, 10, 65_536, 50, 80, 150, 100, ("empty",)),
     "dp5_1e5": ("dp", 30, 5, 100_000, 50, 77, 150, 100, ("empty",)),
     "dp5_4e5": ("dp", 30, 5, 400_000, 50, 77, 150, 100, ("empty",)),
     "dp10_1e5": ("dp", 30, 10, 100_000, 50, 78, 150, 100, ("empty",)),

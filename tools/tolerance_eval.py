@@ -28,7 +28,7 @@ from tolerance_cases import CASES, CHAIN_SEEDS, compare, initial_labels, load_fi
 
 def default_batch(sampler, N):
     """include/bmm_mcmc.h bmm_default_batch (tests/test_capi_cpu.py holds the library to the same rule)"""
-    div = (16 if sampler == "dp" else 8) // (2 if N >= 2 ** 16 else 1)
+    div = 4 if N >= 2 ** 16 else (16 if sampler == "dp" else 8)
     return max(1, N // div)
 
 
