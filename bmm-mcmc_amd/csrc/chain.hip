@@ -1001,9 +1001,11 @@ int pick_kernel(bmm_chain* c) {
         const int nt = atoi(dbg);
         if (resample_fn f = resample_kernel_at(p.KT, nt, minus, c->bits)) { c->fn = f; c->NT = nt; }
     } else if (c->bits && split == 1 && !alt) {
-        // a batch that cannot give every CU a workgroup of the default size gets smaller ones
+        // a batch that cannot give every CU a workgroup of the default size gets smaller ones -- as long as they
+        // still hold the whole batch in one round (250 000 observations: 245 workgroups of 1024 threads, one chunk
+        // per wave, beat 256 of 768 where a quarter of the waves takes a second chunk: north-star kernel -6 %)
         for (int nt : {768, 512}) {
-            if ((c->batch + c->NT - 1) / c->NT >= c->num_cus || nt >= c->NT) continue;
+            if ((c->batch + c->NT - 1) / c->NT >= c->num_cus || nt >= c->NT || (c->batch + nt - 1) / nt > c->num_cus) continue;
             if (resample_fn f = resample_kernel_at(p.KT, nt, minus, true)) { c->fn = f; c->NT = nt; }
         }
     }
