@@ -302,7 +302,7 @@ struct PhaseClock {
 };
 
 // accumulator counts the resample kernel is instantiated for
-const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+const int kKT[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 52, 56, 64};  // (52: maxK = 50, BASELINE config 4)
 // workgroup size by accumulator count: the VGPR budget per lane is 512 / (waves per SIMD)
 constexpr int kThreadsSmall = 1024;  // KT <= 12: 128 VGPRs
 constexpr int kThreadsMid = 768;     // KT 16, 20: 168 VGPRs
@@ -351,6 +351,7 @@ resample_fn resample_kernel_m(int kt) {
         case 32: return k_resample<32, BITS ? kThreadsMid : kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
         case 40: return k_resample<40, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
         case 48: return k_resample<48, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
+        case 52: return k_resample<52, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
         case 56: return k_resample<56, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
         case 64: return k_resample<64, kThreadsLarge, MINUS, 16, BITS, 1, false, GW>;
     }
@@ -370,6 +371,7 @@ resample_fn resample_kernel_small(int kt) {
         case 32: return k_resample<32, 256, MINUS, 16, BITS>;
         case 40: return k_resample<40, 256, MINUS, 16, BITS>;
         case 48: return k_resample<48, 256, MINUS, 16, BITS>;
+        case 52: return k_resample<52, 256, MINUS, 16, BITS>;
         case 56: return k_resample<56, 256, MINUS, 16, BITS>;
         case 64: return k_resample<64, 256, MINUS, 16, BITS>;
     }
@@ -419,6 +421,7 @@ resample_fn resample_kernel_split_w(int kt) {
         case 32: return GW == kGroupW ? k_resample<32, kThreadsSplit, MINUS, 16, true, 2, false, kGroupW> : nullptr;
         case 40: return k_resample<40, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
         case 48: return k_resample<48, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
+        case 52: return k_resample<52, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
         case 56: return k_resample<56, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
         case 64: return k_resample<64, kThreadsSplit, MINUS, 16, true, 2, false, GW>;
     }
@@ -443,6 +446,7 @@ resample_fn resample_kernel_emit_m(int kt) {
         case 32: return k_resample<32, kThreadsMid, MINUS, 16, true, 1, true, GW>;
         case 40: return k_resample<40, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
         case 48: return k_resample<48, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
+        case 52: return k_resample<52, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
         case 56: return k_resample<56, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
         case 64: return k_resample<64, kThreadsLarge, MINUS, 16, true, 1, true, GW>;
     }

@@ -98,7 +98,7 @@ def test_wide_category_counts_two_lanes_per_observation(oracle, dbg_lib, nosplit
         dbg_lib.setenv("BMM_DEBUG_NOSPLIT", "1")
     else:
         dbg_lib.delenv("BMM_DEBUG_NOSPLIT", raising=False)
-    for N, P, K, batch in [(3000, 40, 40, 700), (2011, 20, 64, 2011), (1500, 33, 56, 97)]:
+    for N, P, K, batch in [(3000, 40, 40, 700), (2011, 20, 64, 2011), (1500, 33, 56, 97), (2600, 50, 50, 650), (1800, 25, 52, 1800)]:   # (50, 52: the 52-accumulator kernels)
         X, _, _, _ = synth(N, P, 4, K)
         z0 = _z0(N, K, 3)
         got = bm.gibbs_collapsed(X, 6, K, burnin=0, seed=77, batch=batch, initial_K=z0)
@@ -106,10 +106,11 @@ def test_wide_category_counts_two_lanes_per_observation(oracle, dbg_lib, nosplit
         for k in ("z", "theta", "alpha"):
             assert np.array_equal(got[k], want[k], equal_nan=True), (k, N, P, K)
     X, _, _, _ = synth(4000, 24, 5, 9)
-    got = bm.gibbs_dp(X, 8, burnin=0, maxK=47, seed=31, batch=333)
-    want = oracle.dp(X, 8, 0.0, 0.5, 0.5, 1, 1, 0, 47, seed=31, batch=333)
-    for k in ("z", "theta", "alpha"):
-        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    for maxK in (47, 51):
+        got = bm.gibbs_dp(X, 8, burnin=0, maxK=maxK, seed=31, batch=333)
+        want = oracle.dp(X, 8, 0.0, 0.5, 0.5, 1, 1, 0, maxK, seed=31, batch=333)
+        for k in ("z", "theta", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, maxK)
     rng = np.random.default_rng(4)
     pi0 = rng.dirichlet(np.ones(40))
     th0 = rng.random((40, 30))
