@@ -1,5 +1,5 @@
 """Shapes and summaries of the batch-tolerance fixtures (tests/golden/tolerance_*.json): shared by the generator
-(tests/golden/make_tolerance_fixtures.py, oracle at batch = 1), the CPU preview (tools/tolerance_eval.py, oracle at
+(tests/golden/make_tolerance_fixtures.py, oracle at batch = 1), the CPU preview (tests/tools/tolerance_eval.py, oracle at
 any batch) and the GPU tests (tests/test_gpu_tolerance_fixtures.py, HIP path at the default batch)."""
 import json
 import os

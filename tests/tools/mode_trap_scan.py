@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """From a uniformly random allocation, how often does a chain end in the generating mode (every generating
 component held by exactly one cluster) -- the sequential scan (batch 1) against the default batch (N/8)?
-Oracle on CPU (the HIP path equals it bit for bit at equal batch and seed).  tools/mode_trap_scan.py N seeds sweeps
+Oracle on CPU (the HIP path equals it bit for bit at equal batch and seed).  tests/tools/mode_trap_scan.py N seeds sweeps
 Answers whether the batch makes the burn-in from a random start more trap-prone (tests/test_gpu_tolerance_fixtures.py
 sees 6 of 12 against 8 of 12 over its four shapes x three seeds: too few to tell)."""
 import json
@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bmm_mcmc_amd import synth  # noqa: E402

@@ -5,12 +5,12 @@ chain checked against its oracle chain, hundreds of times in one process.  Round
 single-shot tests had passed over: a workgroup of a table-building launch that starts late read part of its own
 launch's counts (one mismatch in twenty iterations; tests/test_gpu_layouts.py now holds a workgroup back on purpose),
 and a process that creates and destroys four hardware-queue streams per call can hang inside the runtime's queue
-creation (the streams are pooled since).  ITERS=250 WATCHDOG=110 timeout -k 5 130 python tools/multi_stress.py full
+creation (the streams are pooled since).  ITERS=250 WATCHDOG=110 timeout -k 5 130 python tests/tools/multi_stress.py full
 prints one line per iteration, the mismatch counts of the three resident chains; the watchdog dumps the Python stack
 and exits when the loop stops."""
 import os, sys, faulthandler
 faulthandler.dump_traceback_later(int(os.environ.get("WATCHDOG", "100")), exit=True)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["BMM_DEBUG_FAKE_DEVICES"] = "2"
 import numpy as np
 from bmm_mcmc_amd import _capi, build

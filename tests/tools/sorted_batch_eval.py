@@ -2,10 +2,10 @@
 """The default batch on data SORTED by generating cluster -- the worst case for batches (the sets the reference bundles
 are sorted; SURVEY.md section 8(d) asks for sorted data as a stress variant): the oracle at N/8 and N/4 against the
 oracle at batch 1 (the sequential scan) from the generating allocation, at the smallest N that gets the N/4 default
-(2^16, K = 20), at C2's shape and at N = 20 000.  CPU only, about a minute: python tools/sorted_batch_eval.py
+(2^16, K = 20), at C2's shape and at N = 20 000.  CPU only, about a minute: python tests/tools/sorted_batch_eval.py
 (output of the round-3 run: profiles/r03/sorted_batch_eval.log)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bmm_mcmc_amd import synth
 from oracle import oracle

@@ -2,8 +2,8 @@
 batch-1 fixtures (tests/golden/tolerance_*.json).  The HIP path equals the oracle bit for bit at equal batch
 and seed (tests/test_gpu_parity.py), so what this prints for batch = "default" is what the GPU test will see.
 
-    python tools/tolerance_eval.py --cases c2,ns --batch default [--threads 6]
-    python tools/tolerance_eval.py --cases c5s --batch N/4        # the worst case of the default's rounding
+    python tests/tools/tolerance_eval.py --cases c2,ns --batch default [--threads 6]
+    python tests/tools/tolerance_eval.py --cases c5s --batch N/4        # the worst case of the default's rounding
 
 --batch: "default" (bmm_default_batch's rule, restated below so that this tool needs no GPU library),
 "N/<d>", or a number.
@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
