@@ -518,7 +518,10 @@ class Chain:
     def kernel_shape(self):
         lds, th, g = _C.c_int(0), _C.c_int(0), _C.c_int(0)
         _capi.check(_capi.lib().bmm_chain_kernel_shape(self._h, _C.byref(lds), _C.byref(th), _C.byref(g)))
-        return {"lds_bytes": lds.value, "threads": th.value, "grid_max": g.value}
+        lanes, own = _C.c_int(0), _C.c_int(0)
+        _capi.check(_capi.lib().bmm_chain_kernel_form(self._h, _C.byref(lanes), _C.byref(own)))
+        return {"lds_bytes": lds.value, "threads": th.value, "grid_max": g.value,
+                "lanes_per_observation": lanes.value, "builds_own_tables": bool(own.value)}
 
 
 def sweep_chains(chains, n):

@@ -21,7 +21,7 @@ SYMBOLS = [
     "bmm_chain_sweeps", "bmm_chain_sweeps_counts", "bmm_chain_sweep_probs", "bmm_chain_set_shard", "bmm_chain_shard_resample",
     "bmm_chain_shard_deltas", "bmm_chain_shard_finish", "bmm_chain_sync", "bmm_chain_sweep_index", "bmm_chain_get_labels",
     "bmm_chain_get_counts", "bmm_chain_get_alpha", "bmm_chain_get_params", "bmm_chain_profile",
-    "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_chain_batch", "bmm_device_math", "bmm_device_variates",
+    "bmm_chain_profile_read", "bmm_chain_kernel_shape", "bmm_chain_kernel_form", "bmm_chain_batch", "bmm_device_math", "bmm_device_variates",
     "bmm_device_count", "bmm_collapsed_run_probs", "bmm_dp_run_probs", "bmm_sb_run_probs", "bmm_full_run_probs",
     "bmm_multi_run", "bmm_multi_selfcheck", "bmm_chains_sweeps", "bmm_chain_share_data", "bmm_chain_planes",
     "bmm_chain_planes_filled", "bmm_chain_shard_resample_async", "bmm_chain_stream",

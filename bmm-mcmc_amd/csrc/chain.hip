@@ -993,7 +993,7 @@ int pick_kernel(bmm_chain* c) {
     // shape by batch: 125 000 two-lane +11 %, 162 500 +11 %, 200 000 -2.5 %, 250 000 -8 % (profiles/r03/ab_smallsplit.log).
     // (not for chains that share their device: several chains' launches fill the chip between them, and then
     // the one-lane form's lower total work wins -- four north-star chains: 14.8 k against 12.1 k sweeps/s)
-    const bool short_launch = BMM_SMALL_SPLIT && !c->shares_device && p.KT >= 16 && !alt && c->batch < (int64_t)c->num_cus * kThreadsMid;
+    const bool short_launch = BMM_SMALL_SPLIT && !c->shares_device && p.KT >= 16 && !alt && (c->batch < (int64_t)c->num_cus * kThreadsMid || dbg_env("BMM_DEBUG_SPLIT"));
     if (c->bits && (p.KT > 32 || short_launch) && minus != 2 && !dbg_env("BMM_DEBUG_NOSPLIT")) {
         if (resample_fn f = minus ? resample_kernel_split<1>(p.KT, p.W) : resample_kernel_split<0>(p.KT, p.W)) {
             c->fn = f;
@@ -1673,6 +1673,13 @@ int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int
     if (lds_bytes) *lds_bytes = (int)c->lds_bytes;
     if (threads) *threads = c->NT;
     if (grid_max) *grid_max = c->grid_max;
+    return BMM_OK;
+}
+
+int bmm_chain_kernel_form(const bmm_chain* c, int* lanes_per_observation, int* builds_own_tables) {
+    if (!c) return set_err(BMM_E_ARG, "null chain");
+    if (lanes_per_observation) *lanes_per_observation = c->generic || c->OT <= 0 ? 1 : c->NT / c->OT;
+    if (builds_own_tables) *builds_own_tables = c->self_tables ? 1 : 0;
     return BMM_OK;
 }
 

@@ -317,6 +317,11 @@ int bmm_chain_profile_read(bmm_chain* c, double* resample_ms, int64_t* resample_
 int64_t bmm_chain_batch(const bmm_chain* c);
 /* bytes of dynamic LDS and threads per workgroup the resample kernel uses for this shape */
 int bmm_chain_kernel_shape(const bmm_chain* c, int* lds_bytes, int* threads, int* grid_max);
+/* ... and its form: lanes of a wave per observation (1, or 2: two lanes share an observation, each scoring half
+ * of the categories -- above 32 accumulators, and for launches too short to fill the chip otherwise), and whether
+ * the resample workgroups build the table image themselves (small finite-sampler shapes: no table kernel between
+ * batches).  Which form runs never changes a chain's values. */
+int bmm_chain_kernel_form(const bmm_chain* c, int* lanes_per_observation, int* builds_own_tables);
 
 /* ---- device self-checks used by the parity tests (op: 0 log, 1 exp, 2 div by in2, 3 sqrt,
  * 4 the draw's weight exponential expw; elementwise over n doubles, evaluated on the GPU with the

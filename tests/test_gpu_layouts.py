@@ -215,3 +215,25 @@ def test_self_built_tables_with_a_workgroup_that_starts_late(oracle, dbg_lib):
         assert np.array_equal(z, want["z"][0]), (N, P, K, batch, int((z != want["z"][0]).sum()))
         assert np.array_equal(nk, np.bincount(z - 1, minlength=K))
         assert np.array_equal(S, np.stack([X[z == k + 1].sum(axis=0) for k in range(K)]))
+
+
+def test_kernel_forms_at_the_benchmark_shapes():
+    """Which form of the resample kernel a shape and batch get (pick_kernel) -- never visible in a chain's values, so
+    held here: the measured rules of profiles/r03/ab_smallsplit.log and ab_self_tables.log at the shapes they were
+    measured on (an MI355X: 256 CUs)."""
+    def form(sampler, N, P, K, batch=0):
+        with bm.Chain(sampler, N, P, K, seed=1, batch=batch) as ch:
+            s = ch.kernel_shape()
+            return ch.batch, s["threads"], s["lanes_per_observation"], s["builds_own_tables"]
+    # north-star shape: N/4 = 250 000 observations per launch fill the chip with one-lane workgroups of 1024 threads;
+    # at 125 000 (the N/8 of the first half of round 3) two lanes per observation
+    assert form("collapsed", 1_000_000, 50, 20) == (250_000, 1024, 1, False)
+    assert form("collapsed", 1_000_000, 50, 20, batch=125_000) == (125_000, 1024, 2, False)
+    assert form("collapsed", 1_000_000, 50, 20, batch=200_000)[2] == 1          # from 196 608 on: one lane
+    # c3 (32 accumulators): 250 000 -> one-lane workgroups of 768 threads; 125 000 -> two lanes
+    assert form("dp", 1_000_000, 50, 30) == (250_000, 768, 1, False)
+    assert form("dp", 1_000_000, 50, 30, batch=125_000)[2] == 2
+    # c2: workgroups of 256 threads that build their own tables; C5 and c4: the big kernels
+    assert form("collapsed", 100_000, 20, 3) == (25_000, 256, 1, True)
+    assert form("collapsed", 10_000_000, 100, 20)[:3] == (2_500_000, 1024, 1)
+    assert form("stickbreaking", 1_000_000, 50, 50)[1:3] == (1024, 2)           # 52 accumulators: always two lanes
