@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <emmintrin.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -31,6 +32,10 @@
 #include <thread>
 #include <utility>
 #include <vector>
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 
 #include "../../include/bmm_mcmc.h"
 #include "kernels.hip.h"
@@ -1870,6 +1875,22 @@ int trace_out(bmm_chain* c, int32_t* z_out, PhaseClock* clock) {
     std::unique_ptr<HostCrew> own_crew;  // a resident chain's trace (no *_run call around it)
     HostCrew* crew = c->crew;
     if (!crew) { own_crew.reset(new HostCrew()); crew = own_crew.get(); }
+    // The caller's S x N matrix is usually fresh (R's allocMatrix, numpy.empty): its pages are not there yet, and
+    // taking the page faults inside the widening loop makes that loop fault-bound (1.08 GB at C5: 14-21 ms).  The
+    // host is idle while the device still runs the sweeps enqueued ahead of this call's blocks, so the crew takes
+    // the faults now (MADV_POPULATE_WRITE, Linux 5.14; anything else it answers is ignored: the widening then
+    // faults as before).  Every cell of the matrix is overwritten below.
+    {
+        const uintptr_t page = 4096;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(z_out) + page - 1) & ~(page - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(z_out) + (size_t)S * (size_t)N * sizeof(int32_t)) & ~(page - 1);
+        if (hi > lo + (64 << 20) / 64) {  // from a megabyte up
+            const int64_t pages = (int64_t)((hi - lo) / page);
+            crew->begin(pages, 256, 1, [lo, page](int64_t a, int64_t b) {
+                (void)madvise(reinterpret_cast<void*>(lo + (uintptr_t)a * page), (size_t)(b - a) * page, MADV_POPULATE_WRITE);
+            });
+        }
+    }
     auto consume = [&](int64_t blk) {
         const int64_t i0 = blk * B, rows = N - i0 < B ? N - i0 : B;
         int32_t* const dst = z_out + (size_t)i0 * S;
