@@ -553,6 +553,7 @@ struct bmm_chain {
     int32_t* dNkTrace = nullptr;  // [n][K] cluster sizes per sweep of the current sweeps_counts call
     int nk_trace_base = 0;        // sweep index of its row 0
     unsigned long long* dDiag = nullptr;
+    int* dViable = nullptr;       // stick-breaking / full: the cluster count the concentration's update uses (k_sb_params -> k_sb_theta_tables)
     int* dSelfDone = nullptr;     // SELF kernels: workgroups of the running launch that have read the statistics
     int32_t *dDNkAlt = nullptr, *dDSAlt = nullptr;  // ... and the second set of delta accumulators (self_fold_prev)
     int* dDbgFlag = nullptr;      // -DBMM_DEBUG_HOOKS: raised by a kernel that meets a label out of range
@@ -787,6 +788,7 @@ int chain_alloc(bmm_chain* c) {
         c->dDiag = a.take<unsigned long long>(16);
 #endif
         c->dSelfDone = a.take<int>(1);
+        c->dViable = a.take<int>(1);
         c->dDNkAlt = a.take<int32_t>(nn * kDeltaReps);
         c->dDSAlt = a.take<int32_t>(ns * kDeltaReps);
 #ifdef BMM_DEBUG_HOOKS
@@ -948,10 +950,11 @@ int enqueue_sweep(bmm_chain* c, int j, int phase = 0) {
         if (phase == 1) return launch_reduce_deltas(c);  // sharded chain: the caller all-reduces replica 0 now
         hipLaunchKernelGGL(k_sb_params, dim3(1), dim3(1024), 0, c->stream, p, c->dNk, c->dS, c->dDNk,
                            c->dDS, c->dAlpha, c->dPi, (uint32_t)j, rec ? c->dPiTrace + s : nullptr, c->S,
-                           al_tr, nk_tr);
+                           c->dViable, nk_tr);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(256), 0, c->stream, p, c->dNk, c->dS,
-                           c->dPi, c->dTheta, 1, (uint32_t)j, th_tr, c->dTab);
+        // (one workgroup more than clusters: the concentration's update runs beside the theta draws)
+        hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT + 1), dim3(256), 0, c->stream, p, c->dNk, c->dS,
+                           c->dPi, c->dTheta, 1, (uint32_t)j, th_tr, c->dTab, c->dAlpha, al_tr, c->dViable);
         HIP_TRY(hipGetLastError());
         return BMM_OK;
     }
@@ -1082,7 +1085,8 @@ int chain_start(bmm_chain* c) {
         HIP_TRY(hipGetLastError());
     } else if (explicit_params(p.mode)) {
         hipLaunchKernelGGL(k_sb_theta_tables, dim3(p.KT), dim3(256), 0, c->stream, p, c->dNk, c->dS,
-                           c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab);
+                           c->dPi, c->dTheta, 0, 0u, (double*)nullptr, c->dTab, (double*)nullptr, (double*)nullptr,
+                           (const int*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     c->started = true;

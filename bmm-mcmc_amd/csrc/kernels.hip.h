@@ -267,10 +267,29 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
                                                          const double* __restrict__ pi,
                                                          double* __restrict__ theta, int draw,
                                                          uint32_t sweep, double* __restrict__ theta_trace,
-                                                         double* __restrict__ tab) {
+                                                         double* __restrict__ tab,
+                                                         double* __restrict__ alpha_ptr,
+                                                         double* __restrict__ alpha_trace,
+                                                         const int* __restrict__ viable) {
     // 256 threads: a Beta draw is X / (X + Y) of two gammas on their own streams, so threads 0-127 draw
     // X and log theta for feature d while threads 128-255 draw Y and log(1 - theta): half the latency
     __shared__ double e1[kMaxP], e0[kMaxP], gam[2][kMaxP], cst;
+    if (blockIdx.x == (unsigned)p.KT) {
+        // one workgroup past the clusters' (launched with the draws of a sweep only): the concentration, four
+        // gammas side by side (update_alpha_wave; stickbreaking.cpp:233-235, full_gibbs.cpp:228-230), from the count
+        // k_sb_params left.  Nothing in this kernel reads alpha; the next sweep's k_sb_params does.
+        if (threadIdx.x < 64) {
+            const double alpha_prev = *alpha_ptr;
+            double alpha_new = alpha_prev;
+            if (p.sample_alpha)
+                alpha_new = update_alpha_wave(alpha_prev, p.a, p.b, (double)p.Ntot, *viable, p.seed, sweep, threadIdx.x);
+            if (threadIdx.x == 0) {
+                if (p.sample_alpha) *alpha_ptr = alpha_new;
+                if (alpha_trace) *alpha_trace = alpha_new;
+            }
+        }
+        return;
+    }
     const int k = blockIdx.x;
     const TableLayout L = layout_of(p, false);
     const int P = p.P, K = p.K;
@@ -318,14 +337,13 @@ __global__ __launch_bounds__(256) void k_sb_theta_tables(ChainParams p, const in
 // breaking, K_viable, alpha (stickbreaking.cpp:164-214, 233-235).  One workgroup.
 __global__ __launch_bounds__(1024) void k_sb_params(ChainParams p, int32_t* __restrict__ Nk,
                                                    int32_t* __restrict__ S, int32_t* __restrict__ dNk,
-                                                   int32_t* __restrict__ dS, double* __restrict__ alpha_ptr,
+                                                   int32_t* __restrict__ dS, const double* __restrict__ alpha_ptr,
                                                    double* __restrict__ pi, uint32_t sweep,
                                                    double* __restrict__ pi_trace, int pi_stride,
-                                                   double* __restrict__ alpha_trace,
+                                                   int* __restrict__ viable_out,
                                                    int32_t* __restrict__ nk_trace) {
     __shared__ int32_t ck[kMaxCatsAny];
     __shared__ double v[kMaxCatsAny];
-    __shared__ int sh_viable;
     const int K = p.K, P = p.P;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int32_t n = Nk[k] + delta_take(dNk, k, K);
@@ -377,17 +395,9 @@ __global__ __launch_bounds__(1024) void k_sb_params(ChainParams p, int32_t* __re
                 if (pi_trace) pi_trace[(size_t)k * pi_stride] = pk;
             }
         }
-        sh_viable = viable;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {  // the concentration: four gammas side by side (update_alpha_wave)
-        double alpha_new = alpha_prev;
-        if (p.sample_alpha)
-            alpha_new = update_alpha_wave(alpha_prev, p.a, p.b, (double)p.Ntot, sh_viable, p.seed, sweep, threadIdx.x);
-        if (threadIdx.x == 0) {
-            if (p.sample_alpha) *alpha_ptr = alpha_new;
-            if (alpha_trace) *alpha_trace = alpha_new;
-        }
+        // the concentration's update needs this count and nothing else of the sweep: it runs beside the theta
+        // draws, in a workgroup of its own of the next kernel (k_sb_theta_tables), off this kernel's critical path
+        *viable_out = viable;
     }
 }
 
